@@ -1,0 +1,100 @@
+"""ctypes binding of include/grandplus.h (libgrandplus.so, hand-written HIP for gfx950).
+
+There is no CPU fallback: if the shared library is missing this module raises at first
+use, and if no GPU is visible `gp_graph_create` returns GP_ERR_NO_DEVICE (RuntimeError).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrandplus.so")
+
+GP_OK = 0
+GP_ERR_NULL, GP_ERR_INVALID_CSR, GP_ERR_INVALID_SEED, GP_ERR_INVALID_ARG = 1, 2, 3, 4
+GP_ERR_NO_DEVICE, GP_ERR_HIP, GP_ERR_NOMEM, GP_ERR_OVERFLOW = 5, 6, 7, 8
+GP_MAX_K = 1024
+
+# every symbol include/grandplus.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "gp_abi_version", "gp_strerror", "gp_last_error", "gp_device_count",
+    "gp_graph_create", "gp_graph_destroy", "gp_graph_num_nodes", "gp_graph_nnz",
+    "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_set_option",
+)
+
+
+class GpStats(ctypes.Structure):
+    _fields_ = [
+        ("rows", ctypes.c_int64), ("pushes", ctypes.c_int64), ("edges", ctypes.c_int64),
+        ("filled", ctypes.c_int64), ("support", ctypes.c_int64), ("frontier", ctypes.c_int64),
+        ("lds_levels", ctypes.c_int64), ("global_levels", ctypes.c_int64),
+        ("failed_rows", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
+        ("workgroups", ctypes.c_int32), ("block_threads", ctypes.c_int32),
+        ("lds_bytes", ctypes.c_int32), ("lds_slots", ctypes.c_int32),
+        ("workspace_bytes", ctypes.c_int64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+_LIB = None
+
+
+def lib():
+    """Load libgrandplus.so (once).  Raises RuntimeError if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    i32p, f64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)
+    vp = ctypes.c_void_p
+    L.gp_abi_version.restype = ctypes.c_int
+    L.gp_strerror.restype = ctypes.c_char_p
+    L.gp_strerror.argtypes = [ctypes.c_int]
+    L.gp_last_error.restype = ctypes.c_char_p
+    L.gp_device_count.restype = ctypes.c_int
+    L.gp_graph_create.restype = ctypes.c_int
+    L.gp_graph_create.argtypes = [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.c_int,
+                                  ctypes.POINTER(vp)]
+    L.gp_graph_destroy.restype = None
+    L.gp_graph_destroy.argtypes = [vp]
+    L.gp_graph_num_nodes.restype = ctypes.c_int64
+    L.gp_graph_num_nodes.argtypes = [vp]
+    L.gp_graph_nnz.restype = ctypes.c_int64
+    L.gp_graph_nnz.argtypes = [vp]
+    L.gp_graph_device.restype = ctypes.c_int
+    L.gp_graph_device.argtypes = [vp]
+    L.gp_gfpush.restype = ctypes.c_int
+    L.gp_gfpush.argtypes = [vp, i32p, ctypes.c_int64, f64p, ctypes.c_int, ctypes.c_double,
+                            ctypes.c_int, i32p, i32p, f64p]
+    # device pointers travel as integers (tensor.data_ptr())
+    L.gp_gfpush_device.restype = ctypes.c_int
+    L.gp_gfpush_device.argtypes = [vp, vp, ctypes.c_int64, f64p, ctypes.c_int, ctypes.c_double,
+                                   ctypes.c_int, vp, vp, vp, vp, vp]
+    L.gp_get_stats.restype = ctypes.c_int
+    L.gp_get_stats.argtypes = [vp, ctypes.POINTER(GpStats)]
+    L.gp_set_option.restype = ctypes.c_int
+    L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    if L.gp_abi_version() != 1:
+        raise RuntimeError("libgrandplus.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def raise_for_status(status: int):
+    """Map a C-ABI status to the Python exception the shims document."""
+    if status == GP_OK:
+        return
+    L = lib()
+    detail = L.gp_last_error().decode() or L.gp_strerror(status).decode()
+    if status in (GP_ERR_INVALID_CSR, GP_ERR_INVALID_SEED, GP_ERR_INVALID_ARG, GP_ERR_NULL):
+        raise ValueError(detail)
+    if status == GP_ERR_NOMEM:
+        raise MemoryError(detail)
+    raise RuntimeError(detail)

@@ -1,0 +1,463 @@
+// gfpush.hip -- host side of the C ABI in include/grandplus.h (HIP runtime, gfx950 only).
+//
+// gp_graph_create   <-> Graph::Graph       (reference precompute/graph.h:32-47)
+// gp_gfpush[_device]<-> Graph::gfpush_omp  (reference precompute/graph.h:53-131)
+//
+// The CSR is copied once into HBM and stays resident; each call sizes a per-workgroup
+// scratch area from rigorous bounds (below), launches ONE persistent kernel
+// (gfpush_kernels.hpp) on the caller's stream and brackets it with HIP events.
+#include "gfpush_kernels.hpp"
+#include "grandplus.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace gp;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? GP_ERR_NOMEM : GP_ERR_HIP, "%s: %s",    \
+                        #expr, hipGetErrorString(e_));                                      \
+    } while (0)
+
+struct Workspace {
+    void* base = nullptr; size_t bytes = 0;
+    int n_wg = 0;
+    u64 push_cap = 0, resg_cap = 0, rsv_cap = 0, list_cap = 0;
+    PushEntry* push = nullptr; ResRec* resg = nullptr; RsvRec* rsv = nullptr;
+    int* rsv_list = nullptr; Cand* cand = nullptr;
+    bool dirty = true;            // tables need (re)initialising before the next launch
+};
+
+}  // namespace
+
+struct gp_graph {
+    int device = 0;
+    int64_t n_nodes = 0, nnz = 0;
+    int* d_indptr = nullptr; int* d_indices = nullptr;
+    int no_dangling = 1;
+    int num_cus = 0;
+    // options
+    int block_threads = 1024; int lds_bytes = 160 * 1024; int max_workgroups = 0;
+    int64_t workspace_mb = 65536; int force_global = 0;
+    // per-call state
+    Workspace ws;
+    u64* d_counters = nullptr; u64* h_counters = nullptr;      // pinned host mirror
+    double* d_coef = nullptr; int coef_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;                               // used by the host-buffer entry point
+    bool launched = false; hipStream_t last_stream = nullptr;
+    gp_stats last{};
+    // staging for the host-buffer entry point
+    int* d_seeds = nullptr; int64_t seeds_cap = 0;
+    int *d_row = nullptr, *d_col = nullptr, *d_filled = nullptr; double* d_val = nullptr; int64_t out_cap = 0;
+    int *h_row = nullptr, *h_col = nullptr, *h_filled = nullptr; double* h_val = nullptr; int64_t hout_cap = 0;
+    int64_t hfilled_cap = 0, dfilled_cap = 0;
+};
+
+namespace {
+
+template <int BLOCK> int launch_kernel(const KParams& kp, int n_wg, int lds_bytes, hipStream_t s) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gfpush_kernel<BLOCK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(gfpush_kernel<BLOCK>, dim3(n_wg), dim3(BLOCK), lds_bytes, s, kp);
+    HIP_TRY(hipGetLastError());
+    return GP_OK;
+}
+
+template <int BLOCK> int resident_blocks(int lds_bytes, int* out) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gfpush_kernel<BLOCK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gfpush_kernel<BLOCK>, BLOCK, lds_bytes));
+    *out = std::max(nb, 1);
+    return GP_OK;
+}
+
+void free_workspace(Workspace& w) {
+    if (w.base) (void)hipFree(w.base);
+    w = Workspace();
+}
+
+// Rigorous per-workgroup bounds (u2.62 shares are floor(r/deg), so the residue mass of a
+// level never exceeds 1.0, and a pushed node has deg <= r/rmax up to one fp64 rounding):
+//   E_max  = edges traversed in one level  <= min(nnz, 1.001/rmax + 16)
+//   F_max  = frontier size of one level    <= min(N, E_max) + 1          (+1: dangling -> seed)
+//   support of the reserve map             <= min(N, 1 + L*F_max)
+int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
+    const double nnz_d = (double)g->nnz, n_d = (double)g->n_nodes;
+    double e_max = nnz_d;
+    if (rmax > 0.0) e_max = std::min(nnz_d, std::floor(1.001 / rmax) + 16.0);
+    const double f_max = std::min(n_d, e_max) + 1.0;
+    const double L = (double)(n_coef - 1);
+    const double supp = std::max(1.0, std::min(n_d, 1.0 + L * f_max));
+    const u64 resg_cap = (u64)std::max(2048.0, 2.0 * f_max);
+    const u64 rsv_cap = (u64)std::max(2048.0, 2.0 * supp);
+    const u64 list_cap = (u64)supp + 1;
+    const u64 push_cap = (u64)(f_max + e_max / kSplitLen + 2.0);
+    if (resg_cap > 0xFFFFFFF0ull || rsv_cap > 0xFFFFFFF0ull)
+        return fail(GP_ERR_INVALID_ARG, "workspace bound exceeds 32-bit slot space");
+    const size_t per_wg = 16 * (size_t)(push_cap + resg_cap + rsv_cap + list_cap) + 4 * (size_t)list_cap + 64;
+    const size_t budget = (size_t)g->workspace_mb << 20;
+    int n_wg = n_wg_wanted;
+    if ((size_t)n_wg * per_wg > budget) n_wg = (int)std::max<size_t>(1, budget / per_wg);
+
+    Workspace& w = g->ws;
+    const bool fits = w.base && w.n_wg >= n_wg && w.push_cap >= push_cap && w.resg_cap >= resg_cap &&
+                      w.rsv_cap >= rsv_cap && w.list_cap >= list_cap;
+    if (!fits) {
+        free_workspace(w);
+        const size_t total = (size_t)n_wg * per_wg + 4096;
+        hipError_t e = hipMalloc(&w.base, total);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(GP_ERR_NOMEM, "hipMalloc(%zu bytes of gfpush workspace): %s", total, hipGetErrorString(e));
+        }
+        w.bytes = total; w.n_wg = n_wg;
+        w.push_cap = push_cap; w.resg_cap = resg_cap; w.rsv_cap = rsv_cap; w.list_cap = list_cap;
+        char* p = (char*)w.base;
+        w.push = (PushEntry*)p; p += 16 * (size_t)n_wg * push_cap;
+        w.resg = (ResRec*)p;    p += 16 * (size_t)n_wg * resg_cap;
+        w.rsv = (RsvRec*)p;     p += 16 * (size_t)n_wg * rsv_cap;
+        w.cand = (Cand*)p;      p += 16 * (size_t)n_wg * list_cap;
+        w.rsv_list = (int*)p;
+        w.dirty = true;
+    }
+    return GP_OK;
+}
+
+int check_call_args(const gp_graph* g, int64_t n_seeds, const double* coef, int n_coef, double rmax, int K) {
+    if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
+    if (!coef) return fail(GP_ERR_NULL, "coef is NULL");
+    if (n_seeds < 0) return fail(GP_ERR_INVALID_ARG, "n_seeds = %lld < 0", (long long)n_seeds);
+    if (n_coef < 1) return fail(GP_ERR_INVALID_ARG, "coef must hold at least one level (got %d)", n_coef);
+    if (K < 1 || K > GP_MAX_K) return fail(GP_ERR_INVALID_ARG, "K = %d outside [1, %d]", K, GP_MAX_K);
+    if (!(rmax >= 0.0) || !std::isfinite(rmax)) return fail(GP_ERR_INVALID_ARG, "rmax must be finite and >= 0");
+    for (int i = 0; i < n_coef; ++i)
+        if (!std::isfinite(coef[i])) return fail(GP_ERR_INVALID_ARG, "coef[%d] is not finite", i);
+    if (n_seeds > 0 && n_seeds * (int64_t)K / K != n_seeds) return fail(GP_ERR_INVALID_ARG, "n_seeds*K overflows");
+    return GP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gp_abi_version(void) { return GP_ABI_VERSION; }
+
+const char* gp_strerror(int status) {
+    switch (status) {
+        case GP_OK: return "ok";
+        case GP_ERR_NULL: return "null pointer";
+        case GP_ERR_INVALID_CSR: return "invalid CSR";
+        case GP_ERR_INVALID_SEED: return "seed out of range";
+        case GP_ERR_INVALID_ARG: return "invalid argument";
+        case GP_ERR_NO_DEVICE: return "no usable HIP device";
+        case GP_ERR_HIP: return "HIP runtime error";
+        case GP_ERR_NOMEM: return "out of memory";
+        case GP_ERR_OVERFLOW: return "row exceeded a workspace bound";
+        default: return "unknown status";
+    }
+}
+
+const char* gp_last_error(void) { return g_last_error.c_str(); }
+
+int gp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indices, int64_t nnz,
+                    int device, gp_graph** out)
+{
+    g_last_error.clear();
+    if (!out) return fail(GP_ERR_NULL, "out is NULL");
+    *out = nullptr;
+    if (!indptr || (!indices && nnz > 0)) return fail(GP_ERR_NULL, "indptr/indices is NULL");
+    if (n_nodes < 0 || nnz < 0 || n_nodes >= 2147483647ll || nnz >= 2147483647ll)
+        return fail(GP_ERR_INVALID_CSR, "n_nodes=%lld nnz=%lld outside int32 CSR range", (long long)n_nodes, (long long)nnz);
+    // The reference trusts its input (graph.h:32-47); an out-of-range column would make the
+    // kernel read outside the arrays, so validate once here.
+    if (indptr[0] != 0) return fail(GP_ERR_INVALID_CSR, "indptr[0] = %d, expected 0", indptr[0]);
+    for (int64_t i = 0; i < n_nodes; ++i)
+        if (indptr[i + 1] < indptr[i]) return fail(GP_ERR_INVALID_CSR, "indptr decreases at node %lld", (long long)i);
+    if (indptr[n_nodes] != nnz) return fail(GP_ERR_INVALID_CSR, "indptr[n] = %d but nnz = %lld", indptr[n_nodes], (long long)nnz);
+    int bad = 0, has_dangling = 0;
+#pragma omp parallel for reduction(| : bad)
+    for (int64_t j = 0; j < nnz; ++j) bad |= (indices[j] < 0 || indices[j] >= n_nodes);
+    if (bad) return fail(GP_ERR_INVALID_CSR, "a column id is outside [0, %lld)", (long long)n_nodes);
+    for (int64_t i = 0; i < n_nodes; ++i) has_dangling |= (indptr[i + 1] == indptr[i]);
+
+    const int ndev = gp_device_count();
+    if (ndev <= 0) return fail(GP_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(GP_ERR_NO_DEVICE, "device %d outside [0, %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+
+    gp_graph* g = new (std::nothrow) gp_graph();
+    if (!g) return fail(GP_ERR_NOMEM, "host allocation failed");
+    g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->no_dangling = has_dangling ? 0 : 1;
+    g->num_cus = prop.multiProcessorCount;
+    int rc = GP_OK;
+    auto cleanup = [&](int status) { gp_graph_destroy(g); return status; };
+    if (hipMalloc(&g->d_indptr, sizeof(int) * (size_t)(n_nodes + 1)) != hipSuccess ||
+        hipMalloc(&g->d_indices, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)) != hipSuccess)
+        return cleanup(fail(GP_ERR_NOMEM, "hipMalloc of the CSR (%lld nodes, %lld nnz) failed", (long long)n_nodes, (long long)nnz));
+    if (hipMemcpy(g->d_indptr, indptr, sizeof(int) * (size_t)(n_nodes + 1), hipMemcpyHostToDevice) != hipSuccess ||
+        (nnz > 0 && hipMemcpy(g->d_indices, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess))
+        return cleanup(fail(GP_ERR_HIP, "CSR upload failed"));
+    if (hipMalloc(&g->d_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
+        hipHostMalloc(&g->h_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
+        hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess)
+        return cleanup(fail(GP_ERR_HIP, "creating per-graph HIP objects failed"));
+    (void)rc;
+    *out = g;
+    return GP_OK;
+}
+
+void gp_graph_destroy(gp_graph* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->launched) (void)hipStreamSynchronize(g->last_stream);
+    free_workspace(g->ws);
+    if (g->d_indptr) (void)hipFree(g->d_indptr);
+    if (g->d_indices) (void)hipFree(g->d_indices);
+    if (g->d_counters) (void)hipFree(g->d_counters);
+    if (g->h_counters) (void)hipHostFree(g->h_counters);
+    if (g->d_coef) (void)hipFree(g->d_coef);
+    if (g->d_seeds) (void)hipFree(g->d_seeds);
+    if (g->d_row) (void)hipFree(g->d_row);
+    if (g->d_col) (void)hipFree(g->d_col);
+    if (g->d_val) (void)hipFree(g->d_val);
+    if (g->d_filled) (void)hipFree(g->d_filled);
+    if (g->h_row) (void)hipHostFree(g->h_row);
+    if (g->h_col) (void)hipHostFree(g->h_col);
+    if (g->h_val) (void)hipHostFree(g->h_val);
+    if (g->h_filled) (void)hipHostFree(g->h_filled);
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+int64_t gp_graph_num_nodes(const gp_graph* g) { return g ? g->n_nodes : -1; }
+int64_t gp_graph_nnz(const gp_graph* g) { return g ? g->nnz : -1; }
+int gp_graph_device(const gp_graph* g) { return g ? g->device : -1; }
+
+int gp_set_option(gp_graph* g, const char* key, int64_t value) {
+    if (!g || !key) return fail(GP_ERR_NULL, "null argument");
+    const std::string k(key);
+    if (k == "block_threads") {
+        if (value != 256 && value != 512 && value != 1024) return fail(GP_ERR_INVALID_ARG, "block_threads must be 256, 512 or 1024");
+        g->block_threads = (int)value;
+    } else if (k == "lds_bytes") {
+        if (value < 64 * 1024 || value > 160 * 1024) return fail(GP_ERR_INVALID_ARG, "lds_bytes must be in [65536, 163840]");
+        g->lds_bytes = (int)(value & ~15ll);
+    } else if (k == "max_workgroups") {
+        if (value < 0 || value > 65535) return fail(GP_ERR_INVALID_ARG, "max_workgroups must be in [0, 65535]");
+        g->max_workgroups = (int)value;
+    } else if (k == "workspace_mb") {
+        if (value < 1) return fail(GP_ERR_INVALID_ARG, "workspace_mb must be >= 1");
+        g->workspace_mb = value;
+    } else if (k == "force_global") {
+        g->force_global = value ? 1 : 0;
+    } else {
+        return fail(GP_ERR_INVALID_ARG, "unknown option '%s'", key);
+    }
+    return GP_OK;
+}
+
+int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
+                     const double* coef, int n_coef, double rmax, int K,
+                     int32_t* d_row, int32_t* d_col, double* d_val, int32_t* d_filled, void* stream)
+{
+    g_last_error.clear();
+    int rc = check_call_args(g, n_seeds, coef, n_coef, rmax, K);
+    if (rc) return rc;
+    if (n_seeds > 0 && (!d_seeds || !d_row || !d_col || !d_val)) return fail(GP_ERR_NULL, "a device buffer is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (g->launched) HIP_TRY(hipStreamSynchronize(g->last_stream));   // counters / workspace are per graph
+
+    // LDS table geometry: 12 B per slot after the control block; top-K scratch must fit in it
+    const int lds_bytes = g->lds_bytes;
+    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12);
+    if ((size_t)lds_slots * 12 < kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap)
+        return fail(GP_ERR_INVALID_ARG, "lds_bytes too small for K = %d", K);
+
+    int per_cu = 1;
+    switch (g->block_threads) {
+        case 256: rc = resident_blocks<256>(lds_bytes, &per_cu); break;
+        case 512: rc = resident_blocks<512>(lds_bytes, &per_cu); break;
+        default:  rc = resident_blocks<1024>(lds_bytes, &per_cu); break;
+    }
+    if (rc) return rc;
+    int n_wg = g->num_cus * per_cu;
+    if (g->max_workgroups > 0) n_wg = std::min(n_wg, g->max_workgroups);
+    n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(n_wg, n_seeds));
+    rc = ensure_workspace(g, n_coef, rmax, n_wg);
+    if (rc) return rc;
+    Workspace& w = g->ws;
+    n_wg = std::min(n_wg, w.n_wg);
+
+    if (n_coef > g->coef_cap) {
+        if (g->d_coef) (void)hipFree(g->d_coef);
+        g->d_coef = nullptr; g->coef_cap = 0;
+        HIP_TRY(hipMalloc(&g->d_coef, sizeof(double) * (size_t)n_coef));
+        g->coef_cap = n_coef;
+    }
+    HIP_TRY(hipMemcpyAsync(g->d_coef, coef, sizeof(double) * (size_t)n_coef, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * kNumCounters, s));
+    if (w.dirty) {
+        hipLaunchKernelGGL(init_tables_kernel, dim3(4096), dim3(256), 0, s, w.resg,
+                           (u64)w.n_wg * w.resg_cap, w.rsv, (u64)w.n_wg * w.rsv_cap);
+        HIP_TRY(hipGetLastError());
+        w.dirty = false;
+    }
+
+    KParams kp;
+    kp.indptr = g->d_indptr; kp.indices = g->d_indices; kp.n_nodes = (int)g->n_nodes;
+    kp.seeds = d_seeds; kp.n_seeds = n_seeds;
+    kp.coef = g->d_coef; kp.n_coef = n_coef; kp.rmax = rmax; kp.K = K;
+    kp.out_row = d_row; kp.out_col = d_col; kp.out_val = d_val; kp.out_filled = d_filled;
+    kp.push = w.push; kp.push_cap = w.push_cap;
+    kp.resg = w.resg; kp.resg_cap = w.resg_cap;
+    kp.rsv = w.rsv;   kp.rsv_cap = w.rsv_cap;
+    kp.rsv_list = w.rsv_list; kp.list_cap = w.list_cap;
+    kp.cand = w.cand;
+    kp.counters = g->d_counters;
+    kp.lds_slots = lds_slots;
+    kp.no_dangling = g->no_dangling;
+    kp.force_global = g->force_global;
+
+    HIP_TRY(hipEventRecord(g->ev0, s));
+    if (n_seeds > 0) {
+        switch (g->block_threads) {
+            case 256: rc = launch_kernel<256>(kp, n_wg, lds_bytes, s); break;
+            case 512: rc = launch_kernel<512>(kp, n_wg, lds_bytes, s); break;
+            default:  rc = launch_kernel<1024>(kp, n_wg, lds_bytes, s); break;
+        }
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(g->ev1, s));
+    HIP_TRY(hipMemcpyAsync(g->h_counters, g->d_counters, sizeof(u64) * kNumCounters, hipMemcpyDeviceToHost, s));
+    g->launched = true; g->last_stream = s;
+    std::memset(&g->last, 0, sizeof g->last);
+    g->last.rows = n_seeds;
+    g->last.workgroups = n_wg; g->last.block_threads = g->block_threads;
+    g->last.lds_bytes = lds_bytes; g->last.lds_slots = (int)lds_slots;
+    g->last.workspace_bytes = (int64_t)w.bytes;
+    return GP_OK;
+}
+
+int gp_get_stats(gp_graph* g, gp_stats* out) {
+    if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
+    if (!g->launched) { if (out) std::memset(out, 0, sizeof *out); return GP_OK; }
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipStreamSynchronize(g->last_stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    gp_stats& s = g->last;
+    s.kernel_ms = ms;
+    s.pushes = (int64_t)g->h_counters[kPushes];
+    s.edges = (int64_t)g->h_counters[kEdges];
+    s.filled = (int64_t)g->h_counters[kFilled];
+    s.support = (int64_t)g->h_counters[kSupport];
+    s.frontier = (int64_t)g->h_counters[kFrontier];
+    s.lds_levels = (int64_t)g->h_counters[kLdsLevels];
+    s.global_levels = (int64_t)g->h_counters[kGlobalLevels];
+    s.failed_rows = (int64_t)g->h_counters[kFailedRows];
+    if (out) *out = s;
+    if (s.failed_rows) {
+        g->ws.dirty = true;
+        return fail(GP_ERR_OVERFLOW, "%lld row(s) hit a workspace bound or had an out-of-range seed", (long long)s.failed_rows);
+    }
+    return GP_OK;
+}
+
+int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
+              const double* coef, int n_coef, double rmax, int K,
+              int32_t* row_idx, int32_t* col_idx, double* value)
+{
+    g_last_error.clear();
+    int rc = check_call_args(g, n_seeds, coef, n_coef, rmax, K);
+    if (rc) return rc;
+    if (n_seeds == 0) return GP_OK;
+    if (!seeds || !row_idx || !col_idx || !value) return fail(GP_ERR_NULL, "a host buffer is NULL");
+    for (int64_t i = 0; i < n_seeds; ++i)
+        if (seeds[i] < 0 || seeds[i] >= g->n_nodes)
+            return fail(GP_ERR_INVALID_SEED, "node_idx[%lld] = %d outside [0, %lld)", (long long)i, seeds[i], (long long)g->n_nodes);
+    HIP_TRY(hipSetDevice(g->device));
+    const int64_t slots = n_seeds * (int64_t)K;
+    if (n_seeds > g->seeds_cap) {
+        if (g->d_seeds) (void)hipFree(g->d_seeds);
+        if (g->d_filled) (void)hipFree(g->d_filled);
+        if (g->h_filled) (void)hipHostFree(g->h_filled);
+        g->d_seeds = nullptr; g->d_filled = nullptr; g->h_filled = nullptr; g->seeds_cap = 0;
+        HIP_TRY(hipMalloc(&g->d_seeds, sizeof(int) * (size_t)n_seeds));
+        HIP_TRY(hipMalloc(&g->d_filled, sizeof(int) * (size_t)n_seeds));
+        HIP_TRY(hipHostMalloc(&g->h_filled, sizeof(int) * (size_t)n_seeds));
+        g->seeds_cap = n_seeds;
+    }
+    if (slots > g->out_cap) {
+        if (g->d_row) (void)hipFree(g->d_row);
+        if (g->d_col) (void)hipFree(g->d_col);
+        if (g->d_val) (void)hipFree(g->d_val);
+        if (g->h_row) (void)hipHostFree(g->h_row);
+        if (g->h_col) (void)hipHostFree(g->h_col);
+        if (g->h_val) (void)hipHostFree(g->h_val);
+        g->d_row = g->d_col = nullptr; g->d_val = nullptr; g->h_row = g->h_col = nullptr; g->h_val = nullptr;
+        g->out_cap = 0;
+        HIP_TRY(hipMalloc(&g->d_row, sizeof(int) * (size_t)slots));
+        HIP_TRY(hipMalloc(&g->d_col, sizeof(int) * (size_t)slots));
+        HIP_TRY(hipMalloc(&g->d_val, sizeof(double) * (size_t)slots));
+        HIP_TRY(hipHostMalloc(&g->h_row, sizeof(int) * (size_t)slots));
+        HIP_TRY(hipHostMalloc(&g->h_col, sizeof(int) * (size_t)slots));
+        HIP_TRY(hipHostMalloc(&g->h_val, sizeof(double) * (size_t)slots));
+        g->out_cap = slots;
+    }
+    hipStream_t s = g->stream;
+    HIP_TRY(hipMemcpyAsync(g->d_seeds, seeds, sizeof(int) * (size_t)n_seeds, hipMemcpyHostToDevice, s));
+    rc = gp_gfpush_device(g, g->d_seeds, n_seeds, coef, n_coef, rmax, K, g->d_row, g->d_col, g->d_val, g->d_filled, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(g->h_filled, g->d_filled, sizeof(int) * (size_t)n_seeds, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(g->h_row, g->d_row, sizeof(int) * (size_t)slots, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(g->h_col, g->d_col, sizeof(int) * (size_t)slots, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(g->h_val, g->d_val, sizeof(double) * (size_t)slots, hipMemcpyDeviceToHost, s));
+    rc = gp_get_stats(g, nullptr);             // synchronises the stream
+    if (rc) return rc;
+    // Write only the filled (v > 0) slots: everything else keeps the caller's contents (graph.h:121).
+#pragma omp parallel for schedule(static)
+    for (int64_t it = 0; it < n_seeds; ++it) {
+        const int64_t o = it * (int64_t)K;
+        const int nf = g->h_filled[it];
+        if (nf <= 0) continue;
+        std::memcpy(row_idx + o, g->h_row + o, sizeof(int) * (size_t)nf);
+        std::memcpy(col_idx + o, g->h_col + o, sizeof(int) * (size_t)nf);
+        std::memcpy(value + o, g->h_val + o, sizeof(double) * (size_t)nf);
+    }
+    return GP_OK;
+}
+
+}  // extern "C"

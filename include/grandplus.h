@@ -1,0 +1,129 @@
+/*
+ * grandplus.h -- C ABI of the MI355X-native GFPush propagation-matrix precompute.
+ *
+ * This is the drop-in boundary for the ONE hot path of THUDM/GRAND-plus: the pybind11
+ * class `propagation.Graph` (reference precompute/propagation.cpp:8-12) whose two
+ * members are `Graph(indptr, indices, seed)` (precompute/graph.h:32-47) and
+ * `gfpush_omp(node_idx, row_idx, col_idx, value, coef, rmax, K)`
+ * (precompute/graph.h:53-131).  Every entry point takes plain pointers and sizes; no
+ * torch / pybind11 / HIP types appear in a signature (streams travel as void*).
+ *
+ * Implemented by grand_plus_amd/libgrandplus.so (grand_plus_amd/csrc/gfpush.hip, hand-written
+ * HIP for gfx950).  There is no CPU fallback: without a usable GPU gp_graph_create
+ * returns GP_ERR_NO_DEVICE.
+ */
+#ifndef GRANDPLUS_H
+#define GRANDPLUS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GP_ABI_VERSION 1
+
+/* Status codes (0 = success).  The Python / pybind11 shims map INVALID_* to
+ * ValueError, NO_DEVICE / HIP / OVERFLOW to RuntimeError, NOMEM to MemoryError. */
+enum {
+    GP_OK                = 0,
+    GP_ERR_NULL          = 1,   /* a required pointer is NULL                                   */
+    GP_ERR_INVALID_CSR   = 2,   /* indptr not monotone / indptr[0]!=0 / indptr[n]!=nnz / column out of range */
+    GP_ERR_INVALID_SEED  = 3,   /* a seed id is outside [0, n_nodes)                            */
+    GP_ERR_INVALID_ARG   = 4,   /* K < 1, K > GP_MAX_K, n_coef < 1, non-finite coef/rmax, rmax < 0, negative size */
+    GP_ERR_NO_DEVICE     = 5,   /* no HIP device / device index out of range                    */
+    GP_ERR_HIP           = 6,   /* a HIP runtime call failed (see gp_last_error)                */
+    GP_ERR_NOMEM         = 7,   /* device or host allocation failed                             */
+    GP_ERR_OVERFLOW      = 8    /* a row exceeded a workspace bound (never expected; rows are not silently wrong) */
+};
+
+#define GP_MAX_K 1024
+
+typedef struct gp_graph gp_graph;   /* opaque: CSR resident in one GPU's HBM + workspaces */
+
+/* Counters of the most recent gfpush call on a graph (all exact, summed over its rows). */
+typedef struct gp_stats {
+    int64_t rows;            /* seeds processed                                                  */
+    int64_t pushes;          /* P: (node, level) pushes        -- graph.h:94 branch taken        */
+    int64_t edges;           /* E: sum of deg over the pushes  -- graph.h:96-99 iterations       */
+    int64_t filled;          /* output slots written (v > 0)   -- graph.h:121                    */
+    int64_t support;         /* sum over rows of reserve-map size -- graph.h:111                 */
+    int64_t frontier;        /* sum over rows and levels of frontier size                        */
+    int64_t lds_levels;      /* levels whose residue table lived in LDS                          */
+    int64_t global_levels;   /* levels whose residue table lived in the per-workgroup HBM table  */
+    int64_t failed_rows;     /* rows that hit a workspace bound (=> GP_ERR_OVERFLOW)             */
+    double  kernel_ms;       /* HIP-event time of the gfpush kernel on its stream                */
+    int32_t workgroups;      /* persistent workgroups launched                                   */
+    int32_t block_threads;   /* threads per workgroup                                            */
+    int32_t lds_bytes;       /* dynamic LDS per workgroup                                        */
+    int32_t lds_slots;       /* residue-table slots that fit in that LDS                         */
+    int64_t workspace_bytes; /* HBM scratch held for this configuration                          */
+} gp_stats;
+
+/* ABI / build information. */
+int         gp_abi_version(void);
+const char* gp_strerror(int status);
+const char* gp_last_error(void);          /* thread-local detail of the last failure ("" if none) */
+int         gp_device_count(void);        /* number of visible HIP devices (0 if none)           */
+
+/*
+ * Replaces Graph::Graph (graph.h:32-47).  Validates the CSR (the reference does not), copies
+ * indptr/indices to `device`'s HBM (the reference borrows the caller's buffers: graph.h:35-36;
+ * here the caller may free them after the call) and derives degrees on the fly from indptr
+ * (graph.h:42-45).  The reference's unused `seed` argument (graph.h:40) is accepted by the
+ * shims and dropped before this call.
+ */
+int gp_graph_create(const int32_t* indptr, int64_t n_nodes,
+                    const int32_t* indices, int64_t nnz,
+                    int device, gp_graph** out);
+
+void gp_graph_destroy(gp_graph* g);
+
+int64_t gp_graph_num_nodes(const gp_graph* g);
+int64_t gp_graph_nnz(const gp_graph* g);
+int     gp_graph_device(const gp_graph* g);
+
+/*
+ * Replaces Graph::gfpush_omp (graph.h:53-131) with HOST buffers, exactly as the pybind11
+ * surface hands them over: seeds int32[S]; row_idx/col_idx int32[S*K], value f64[S*K]
+ * caller-allocated and written IN PLACE at slot it*K+i (graph.h:120); only slots with
+ * v > 0 are written (graph.h:121), everything else keeps the caller's contents.  Within a row
+ * the filled slots are i = 0..filled-1 ordered by (value desc, column asc) -- the reference
+ * leaves that order unspecified (nth_element, graph.h:115).  Synchronous.
+ */
+int gp_gfpush(gp_graph* g,
+              const int32_t* seeds, int64_t n_seeds,
+              const double* coef, int n_coef, double rmax, int K,
+              int32_t* row_idx, int32_t* col_idx, double* value);
+
+/*
+ * Same computation with DEVICE buffers on g's GPU, enqueued on `stream` (a hipStream_t
+ * passed as void*; NULL = the default stream) and NOT synchronised: the form bench.py and
+ * the multi-GPU driver use (inputs already resident in HBM, RCCL all-gather consumes the
+ * outputs on device).  d_row/d_col/d_val are [S*K]; slots i >= d_filled[it] of a row are left
+ * untouched.  d_filled is int32[S] (may be NULL).  coef is a HOST array (n_coef doubles).
+ */
+int gp_gfpush_device(gp_graph* g,
+                     const int32_t* d_seeds, int64_t n_seeds,
+                     const double* coef, int n_coef, double rmax, int K,
+                     int32_t* d_row, int32_t* d_col, double* d_val, int32_t* d_filled,
+                     void* stream);
+
+/* Waits for the last gfpush on g and returns its counters (GP_ERR_OVERFLOW if a row failed). */
+int gp_get_stats(gp_graph* g, gp_stats* out);
+
+/*
+ * Tuning knobs (all optional; defaults are chosen for MI355X):
+ *   "block_threads"   256 | 512 | 1024      threads per persistent workgroup
+ *   "lds_bytes"       dynamic LDS per workgroup (<= 163840)
+ *   "max_workgroups"  upper bound on persistent workgroups (0 = CUs x resident blocks)
+ *   "workspace_mb"    HBM scratch budget in MiB (default 65536)
+ *   "force_global"    1 = never use the LDS residue table (testing the HBM-table path)
+ * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.
+ */
+int gp_set_option(gp_graph* g, const char* key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRANDPLUS_H */

@@ -20,7 +20,8 @@ GP_MAX_K = 1024
 EXPORTS = (
     "gp_abi_version", "gp_strerror", "gp_last_error", "gp_device_count",
     "gp_graph_create", "gp_graph_destroy", "gp_graph_num_nodes", "gp_graph_nnz",
-    "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_set_option",
+    "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
+    "gp_set_option",
 )
 
 
@@ -79,6 +80,8 @@ def lib():
                                    ctypes.c_int, vp, vp, vp, vp, vp]
     L.gp_get_stats.restype = ctypes.c_int
     L.gp_get_stats.argtypes = [vp, ctypes.POINTER(GpStats)]
+    L.gp_reset_stats.restype = ctypes.c_int
+    L.gp_reset_stats.argtypes = [vp]
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     if L.gp_abi_version() != 1:

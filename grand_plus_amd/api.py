@@ -128,8 +128,12 @@ class Graph:
             row.data_ptr(), col.data_ptr(), val.data_ptr(), filled.data_ptr(), ctypes.c_void_p(stream)))
         return row, col, val, filled
 
+    def reset_stats(self):
+        _native.raise_for_status(_native.lib().gp_reset_stats(self._h))
+
     def stats(self):
-        """Counters of the last call (waits for it).  Raises if a row hit a workspace bound."""
+        """Counters since the last reset_stats() (gfpush_omp resets them itself); waits for the
+        outstanding call.  Raises if a row hit a workspace bound."""
         st = _native.GpStats()
         rc = _native.lib().gp_get_stats(self._h, ctypes.byref(st))
         _native.raise_for_status(rc)

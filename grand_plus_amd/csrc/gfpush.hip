@@ -65,6 +65,7 @@ struct gp_graph {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;                               // used by the host-buffer entry point
     bool launched = false; hipStream_t last_stream = nullptr;
+    bool reset_pending = true; int64_t rows_total = 0;
     gp_stats last{};
     // staging for the host-buffer entry point
     int* d_seeds = nullptr; int64_t seeds_cap = 0;
@@ -97,8 +98,10 @@ void free_workspace(Workspace& w) {
     w = Workspace();
 }
 
-// Rigorous per-workgroup bounds (u2.62 shares are floor(r/deg), so the residue mass of a
-// level never exceeds 1.0, and a pushed node has deg <= r/rmax up to one fp64 rounding):
+// Per-workgroup bounds.  The residue mass of a level never exceeds 1.0 (up to fp64 rounding)
+// and a pushed node has deg <= r/rmax, so the degrees pushed in one level sum to <= 1/rmax;
+// the 0.1 % + 16 slack covers the rounding.  A row that still exceeds a bound is reported
+// (GP_ERR_OVERFLOW), never silently truncated.
 //   E_max  = edges traversed in one level  <= min(nnz, 1.001/rmax + 16)
 //   F_max  = frontier size of one level    <= min(N, E_max) + 1          (+1: dangling -> seed)
 //   support of the reserve map             <= min(N, 1 + L*F_max)
@@ -298,7 +301,9 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     if (n_seeds > 0 && (!d_seeds || !d_row || !d_col || !d_val)) return fail(GP_ERR_NULL, "a device buffer is NULL");
     HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = (hipStream_t)stream;
-    if (g->launched) HIP_TRY(hipStreamSynchronize(g->last_stream));   // counters / workspace are per graph
+    // workspace and counters are per graph: launches on one stream are ordered by the stream,
+    // a launch on a DIFFERENT stream first waits for the previous one
+    if (g->launched && g->last_stream != s) HIP_TRY(hipStreamSynchronize(g->last_stream));
 
     // LDS table geometry: 12 B per slot after the control block; top-K scratch must fit in it
     const int lds_bytes = g->lds_bytes;
@@ -328,7 +333,12 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         g->coef_cap = n_coef;
     }
     HIP_TRY(hipMemcpyAsync(g->d_coef, coef, sizeof(double) * (size_t)n_coef, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * kNumCounters, s));
+    if (g->reset_pending) {
+        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * kNumCounters, s));
+        g->reset_pending = false; g->rows_total = 0;
+    } else {
+        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64), s));          // the row queue head only
+    }
     if (w.dirty) {
         hipLaunchKernelGGL(init_tables_kernel, dim3(4096), dim3(256), 0, s, w.resg,
                            (u64)w.n_wg * w.resg_cap, w.rsv, (u64)w.n_wg * w.rsv_cap);
@@ -364,10 +374,17 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     HIP_TRY(hipMemcpyAsync(g->h_counters, g->d_counters, sizeof(u64) * kNumCounters, hipMemcpyDeviceToHost, s));
     g->launched = true; g->last_stream = s;
     std::memset(&g->last, 0, sizeof g->last);
-    g->last.rows = n_seeds;
+    g->rows_total += n_seeds;
+    g->last.rows = g->rows_total;
     g->last.workgroups = n_wg; g->last.block_threads = g->block_threads;
     g->last.lds_bytes = lds_bytes; g->last.lds_slots = (int)lds_slots;
     g->last.workspace_bytes = (int64_t)w.bytes;
+    return GP_OK;
+}
+
+int gp_reset_stats(gp_graph* g) {
+    if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
+    g->reset_pending = true;
     return GP_OK;
 }
 
@@ -438,6 +455,7 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
         g->out_cap = slots;
     }
     hipStream_t s = g->stream;
+    g->reset_pending = true;                   // the host-buffer call reports its own counters
     HIP_TRY(hipMemcpyAsync(g->d_seeds, seeds, sizeof(int) * (size_t)n_seeds, hipMemcpyHostToDevice, s));
     rc = gp_gfpush_device(g, g->d_seeds, n_seeds, coef, n_coef, rmax, K, g->d_row, g->d_col, g->d_val, g->d_filled, s);
     if (rc) return rc;

@@ -41,7 +41,8 @@ enum {
 
 typedef struct gp_graph gp_graph;   /* opaque: CSR resident in one GPU's HBM + workspaces */
 
-/* Counters of the most recent gfpush call on a graph (all exact, summed over its rows). */
+/* Counters accumulated over the gfpush calls on a graph since the last gp_reset_stats
+ * (gp_gfpush resets them itself, so after it they describe that one call).  All exact. */
 typedef struct gp_stats {
     int64_t rows;            /* seeds processed                                                  */
     int64_t pushes;          /* P: (node, level) pushes        -- graph.h:94 branch taken        */
@@ -52,7 +53,7 @@ typedef struct gp_stats {
     int64_t lds_levels;      /* levels whose residue table lived in LDS                          */
     int64_t global_levels;   /* levels whose residue table lived in the per-workgroup HBM table  */
     int64_t failed_rows;     /* rows that hit a workspace bound (=> GP_ERR_OVERFLOW)             */
-    double  kernel_ms;       /* HIP-event time of the gfpush kernel on its stream                */
+    double  kernel_ms;       /* HIP-event time of the LAST gfpush kernel on its stream           */
     int32_t workgroups;      /* persistent workgroups launched                                   */
     int32_t block_threads;   /* threads per workgroup                                            */
     int32_t lds_bytes;       /* dynamic LDS per workgroup                                        */
@@ -109,8 +110,11 @@ int gp_gfpush_device(gp_graph* g,
                      int32_t* d_row, int32_t* d_col, double* d_val, int32_t* d_filled,
                      void* stream);
 
-/* Waits for the last gfpush on g and returns its counters (GP_ERR_OVERFLOW if a row failed). */
+/* Waits for the last gfpush on g and returns the counters (GP_ERR_OVERFLOW if a row failed). */
 int gp_get_stats(gp_graph* g, gp_stats* out);
+
+/* Zeroes the counters at the next gfpush call. */
+int gp_reset_stats(gp_graph* g);
 
 /*
  * Tuning knobs (all optional; defaults are chosen for MI355X):

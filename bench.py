@@ -221,6 +221,9 @@ def main():
                        "lds_bytes": stats["lds_bytes"], "workspace_gb": round(stats["workspace_bytes"] / 2**30, 2),
                        "graph_gen_s": round(t_gen, 2), "csr_upload_s": round(t_upload, 3)},
         }
+        if stats.get("diag_ticks_total"):
+            tot = stats["diag_ticks_total"]
+            line["detail"]["diag_phase_share"] = {k: round(stats[f"diag_ticks_{k}"] / tot, 3) for k in ("scan", "expand", "topk", "scan_hbm", "expand_hbm")}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(indptr, indices, all_seeds[args.warmup * S_step:], recipe, args.cpu_budget_s)
             line["cpu_baseline"] = cb

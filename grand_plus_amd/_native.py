@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrandplus.so")
+# GRANDPLUS_DIAG=1 selects the diagnostic build (in-kernel phase stamps); never the default.
+LIB_PATH = os.path.join(_HERE, "libgrandplus_diag.so" if os.environ.get("GRANDPLUS_DIAG") == "1"
+                        else "libgrandplus.so")
 
 GP_OK = 0
 GP_ERR_NULL, GP_ERR_INVALID_CSR, GP_ERR_INVALID_SEED, GP_ERR_INVALID_ARG = 1, 2, 3, 4
@@ -34,6 +36,9 @@ class GpStats(ctypes.Structure):
         ("workgroups", ctypes.c_int32), ("block_threads", ctypes.c_int32),
         ("lds_bytes", ctypes.c_int32), ("lds_slots", ctypes.c_int32),
         ("workspace_bytes", ctypes.c_int64),
+        ("diag_ticks_scan", ctypes.c_int64), ("diag_ticks_expand", ctypes.c_int64),
+        ("diag_ticks_topk", ctypes.c_int64), ("diag_ticks_total", ctypes.c_int64),
+        ("diag_ticks_scan_hbm", ctypes.c_int64), ("diag_ticks_expand_hbm", ctypes.c_int64),
     ]
 
     def as_dict(self):

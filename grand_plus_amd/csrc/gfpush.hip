@@ -41,10 +41,10 @@ int fail(int status, const char* fmt, ...) {
 struct Workspace {
     void* base = nullptr; size_t bytes = 0;
     int n_wg = 0;
-    u64 push_cap = 0, resg_cap = 0, rsv_cap = 0, list_cap = 0;
-    PushEntry* push = nullptr; ResRec* resg = nullptr; RsvRec* rsv = nullptr;
-    int* rsv_list = nullptr; Cand* cand = nullptr;
-    bool dirty = true;            // tables need (re)initialising before the next launch
+    u64 push_cap = 0, resg_cap = 0, log_cap = 0, cand_cap = 0;
+    PushEntry* push = nullptr; ResRec* resg = nullptr;
+    int* log_key = nullptr; double* log_val = nullptr; Cand* cand = nullptr;
+    bool dirty = true;            // HBM residue tables need (re)initialising before the next launch
 };
 
 }  // namespace
@@ -104,6 +104,7 @@ void free_workspace(Workspace& w) {
 // (GP_ERR_OVERFLOW), never silently truncated.
 //   E_max  = edges traversed in one level  <= min(nnz, 1.001/rmax + 16)
 //   F_max  = frontier size of one level    <= min(N, E_max) + 1          (+1: dangling -> seed)
+//   reserve-log records of a row           <= (L+1) * F_max
 //   support of the reserve map             <= min(N, 1 + L*F_max)
 int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
     const double nnz_d = (double)g->nnz, n_d = (double)g->n_nodes;
@@ -112,20 +113,21 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
     const double f_max = std::min(n_d, e_max) + 1.0;
     const double L = (double)(n_coef - 1);
     const double supp = std::max(1.0, std::min(n_d, 1.0 + L * f_max));
+    const double logn = (L + 1.0) * f_max + 64.0;
+    if (2.0 * f_max > 4.0e9 || logn > 4.0e9)
+        return fail(GP_ERR_INVALID_ARG, "workspace bound exceeds 32-bit record space (order %d, rmax %g)", n_coef - 1, rmax);
     const u64 resg_cap = (u64)std::max(2048.0, 2.0 * f_max);
-    const u64 rsv_cap = (u64)std::max(2048.0, 2.0 * supp);
-    const u64 list_cap = (u64)supp + 1;
+    const u64 log_cap = (u64)logn;
+    const u64 cand_cap = (u64)supp + 1;
     const u64 push_cap = (u64)(f_max + e_max / kSplitLen + 2.0);
-    if (resg_cap > 0xFFFFFFF0ull || rsv_cap > 0xFFFFFFF0ull)
-        return fail(GP_ERR_INVALID_ARG, "workspace bound exceeds 32-bit slot space");
-    const size_t per_wg = 16 * (size_t)(push_cap + resg_cap + rsv_cap + list_cap) + 4 * (size_t)list_cap + 64;
+    const size_t per_wg = 16 * (size_t)(2 * push_cap + resg_cap + cand_cap) + 12 * (size_t)log_cap + 64;
     const size_t budget = (size_t)g->workspace_mb << 20;
     int n_wg = n_wg_wanted;
     if ((size_t)n_wg * per_wg > budget) n_wg = (int)std::max<size_t>(1, budget / per_wg);
 
     Workspace& w = g->ws;
     const bool fits = w.base && w.n_wg >= n_wg && w.push_cap >= push_cap && w.resg_cap >= resg_cap &&
-                      w.rsv_cap >= rsv_cap && w.list_cap >= list_cap;
+                      w.log_cap >= log_cap && w.cand_cap >= cand_cap;
     if (!fits) {
         free_workspace(w);
         const size_t total = (size_t)n_wg * per_wg + 4096;
@@ -135,13 +137,13 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
             return fail(GP_ERR_NOMEM, "hipMalloc(%zu bytes of gfpush workspace): %s", total, hipGetErrorString(e));
         }
         w.bytes = total; w.n_wg = n_wg;
-        w.push_cap = push_cap; w.resg_cap = resg_cap; w.rsv_cap = rsv_cap; w.list_cap = list_cap;
+        w.push_cap = push_cap; w.resg_cap = resg_cap; w.log_cap = log_cap; w.cand_cap = cand_cap;
         char* p = (char*)w.base;
-        w.push = (PushEntry*)p; p += 16 * (size_t)n_wg * push_cap;
+        w.push = (PushEntry*)p; p += 16 * (size_t)n_wg * 2 * push_cap;
         w.resg = (ResRec*)p;    p += 16 * (size_t)n_wg * resg_cap;
-        w.rsv = (RsvRec*)p;     p += 16 * (size_t)n_wg * rsv_cap;
-        w.cand = (Cand*)p;      p += 16 * (size_t)n_wg * list_cap;
-        w.rsv_list = (int*)p;
+        w.cand = (Cand*)p;      p += 16 * (size_t)n_wg * cand_cap;
+        w.log_val = (double*)p; p += 8 * (size_t)n_wg * log_cap;
+        w.log_key = (int*)p;
         w.dirty = true;
     }
     return GP_OK;
@@ -340,8 +342,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64), s));          // the row queue head only
     }
     if (w.dirty) {
-        hipLaunchKernelGGL(init_tables_kernel, dim3(4096), dim3(256), 0, s, w.resg,
-                           (u64)w.n_wg * w.resg_cap, w.rsv, (u64)w.n_wg * w.rsv_cap);
+        hipLaunchKernelGGL(init_tables_kernel, dim3(4096), dim3(256), 0, s, w.resg, (u64)w.n_wg * w.resg_cap);
         HIP_TRY(hipGetLastError());
         w.dirty = false;
     }
@@ -353,9 +354,8 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.out_row = d_row; kp.out_col = d_col; kp.out_val = d_val; kp.out_filled = d_filled;
     kp.push = w.push; kp.push_cap = w.push_cap;
     kp.resg = w.resg; kp.resg_cap = w.resg_cap;
-    kp.rsv = w.rsv;   kp.rsv_cap = w.rsv_cap;
-    kp.rsv_list = w.rsv_list; kp.list_cap = w.list_cap;
-    kp.cand = w.cand;
+    kp.log_key = w.log_key; kp.log_val = w.log_val; kp.log_cap = w.log_cap;
+    kp.cand = w.cand; kp.cand_cap = w.cand_cap;
     kp.counters = g->d_counters;
     kp.lds_slots = lds_slots;
     kp.no_dangling = g->no_dangling;
@@ -405,6 +405,12 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     s.lds_levels = (int64_t)g->h_counters[kLdsLevels];
     s.global_levels = (int64_t)g->h_counters[kGlobalLevels];
     s.failed_rows = (int64_t)g->h_counters[kFailedRows];
+    s.diag_ticks_scan = (int64_t)g->h_counters[kTicksScan];
+    s.diag_ticks_expand = (int64_t)g->h_counters[kTicksExpand];
+    s.diag_ticks_topk = (int64_t)g->h_counters[kTicksTopk];
+    s.diag_ticks_total = (int64_t)g->h_counters[kTicksTotal];
+    s.diag_ticks_scan_hbm = (int64_t)g->h_counters[kTicksScanHbm];
+    s.diag_ticks_expand_hbm = (int64_t)g->h_counters[kTicksExpandHbm];
     if (out) *out = s;
     if (s.failed_rows) {
         g->ws.dirty = true;

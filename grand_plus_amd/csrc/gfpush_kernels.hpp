@@ -27,8 +27,16 @@
 // so their last bits depend on arrival order exactly as the reference's depend on its
 // hash-map iteration order.  Reserve values see one add per node per level, in level order.
 //
-// Reserve map of a row: a per-workgroup open-addressing table in HBM/L2 {node -> fp64} plus
-// an insertion list (so top-K and clean-up cost O(support), not O(capacity)).
+// A level too large for one LDS table is expanded in P hash PARTITIONS: pass p re-reads the
+// (L2-hot) CSR ranges and keeps only targets with part(v) == p, so the table never leaves
+// LDS and no global atomic is issued; only levels needing more than kMaxParts passes use the
+// HBM table.
+//
+// Reserve map of a row: NOT a table while the row runs.  SCAN appends one (node, coef*r)
+// record per frontier node to a per-workgroup LOG (coalesced streaming stores).  At the end
+// of the row the log is summed per node in an LDS hash table (in key partitions when the log
+// is long) whose occupied slots are the top-K candidates.  This replaces ~8 random 64-B
+// accesses per frontier node by 12 streamed bytes.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -45,10 +53,11 @@ constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
 constexpr int    kCtlBytes   = 256;     // control block at the start of dynamic LDS
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
+constexpr u32    kMaxParts   = 8;       // most hash partitions a level is expanded in before using the HBM table
+constexpr u32    kMaxProbe   = 1024;    // an LDS insert that probes this far reports overflow (recoverable)
 
 struct PushEntry { int start; int len; double share; };  // 16 B
 struct ResRec    { int key;   int pad; double val; };    // 16 B  residue table record (HBM)
-struct RsvRec    { int key;   int pad; double val; };    // 16 B  reserve table record (HBM)
 struct Cand      { u64 bits;  int key; int pad;  };      // 16 B  top-K candidate
 
 // Control block (lives in LDS, one per workgroup).
@@ -58,9 +67,10 @@ struct Ctl {
     u32 n_dangling;       // how many dangling nodes were drained this level
     u32 n_push;           // push-list entries of this level
     u32 e_next;           // sum of their lengths = edges the next EXPAND will traverse
-    u32 list_count;       // reserve-map insertions so far (= support)
+    u32 log_count;        // reserve-log records so far
     u32 n_cand;           // top-K candidates (value > 0)
-    u32 fail;             // a bounded probe loop gave up / a list overflowed
+    u32 ovf;              // an LDS table partition overflowed (recoverable: more partitions)
+    u32 fail;             // a workspace bound was exceeded (row is reported, never silently wrong)
     u32 n_sel;            // top-K: selected so far
     u32 n_bucket;         // top-K: members of the tie bucket
     u32 tk_bin;           // top-K: digit chosen this pass
@@ -69,18 +79,29 @@ struct Ctl {
 };
 
 enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
-               kGlobalLevels, kFailedRows, kNumCounters };
+               kGlobalLevels, kFailedRows,
+               kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
+               kNumCounters };
+
+// Phase stamps exist only in the diagnostic build (-DGP_DIAG): thread 0 reads the constant
+// 100 MHz clock at phase boundaries.  The product build compiles them to nothing.
+#ifdef GP_DIAG
+#define GP_STAMP(var) do { if (threadIdx.x == 0) var = wall_clock64(); } while (0)
+#define GP_ACCUM(acc, t0, t1) do { if (threadIdx.x == 0) acc += (t1) - (t0); } while (0)
+#else
+#define GP_STAMP(var) do { } while (0)
+#define GP_ACCUM(acc, t0, t1) do { } while (0)
+#endif
 
 struct KParams {
     const int* indptr; const int* indices; int n_nodes;
     const int* seeds; long long n_seeds;
     const double* coef; int n_coef; double rmax; int K;
     int* out_row; int* out_col; double* out_val; int* out_filled;
-    PushEntry* push; u64 push_cap;       // per-workgroup strides, in records
-    ResRec* resg;    u64 resg_cap;
-    RsvRec* rsv;     u64 rsv_cap;
-    int* rsv_list;   u64 list_cap;
-    Cand* cand;                           // stride = list_cap
+    PushEntry* push; u64 push_cap;       // per-workgroup: 2 buffers of push_cap records (this level / next level)
+    ResRec* resg;    u64 resg_cap;       // per-workgroup HBM residue table
+    int* log_key; double* log_val; u64 log_cap;   // per-workgroup reserve log
+    Cand* cand;      u64 cand_cap;       // per-workgroup top-K candidates
     u64* counters;
     u32 lds_slots;
     int no_dangling;                      // 1 when every node has degree >= 1
@@ -92,7 +113,7 @@ __device__ __forceinline__ u32 hash_a(u32 k) {            // residue tables
     k *= 0x9E3779B1u; k ^= k >> 15; k *= 0x85EBCA77u; k ^= k >> 13;
     return k;
 }
-__device__ __forceinline__ u32 hash_b(u32 k) {            // reserve table (independent of hash_a)
+__device__ __forceinline__ u32 hash_b(u32 k) {            // partition choice (independent of hash_a)
     k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; k *= 0x846CA68Bu; k ^= k >> 16;
     return k;
 }
@@ -145,7 +166,8 @@ __device__ __forceinline__ u32 wave_alloc(u32* lds_counter, u32 n, int lane) {
 // ---------------------------------------------------------------- residue tables
 __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {
     u32 slot = slot_of(hash_a((u32)k), cap);
-    for (u32 probe = 0; probe < cap; ++probe) {
+    const u32 max_probe = cap < kMaxProbe ? cap : kMaxProbe;
+    for (u32 probe = 0; probe < max_probe; ++probe) {
         int cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == kEmpty) {
             int expect = kEmpty;
@@ -185,99 +207,100 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
     return false;
 }
 
-// reserve[k] += add.  Exactly one thread touches a given key per level, so the value update
-// is a plain read-modify-write; only the key claim needs a CAS.
-// Returns 0 = updated, 1 = newly inserted (*new_slot set), -1 = table full.
-__device__ __forceinline__ int rsv_add(RsvRec* tab, u32 cap, int k, double add, u32* new_slot) {
-    u32 slot = slot_of(hash_b((u32)k), cap);
-    for (u32 probe = 0; probe < cap; ++probe) {
-        int cur = ld_l2(&tab[slot].key);
-        if (cur == kEmpty) {
-            int expect = kEmpty;
-            if (__hip_atomic_compare_exchange_strong(&tab[slot].key, &expect, k, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                st_l2(&tab[slot].val, add);                 // 0.0 + add == add exactly
-                *new_slot = slot;
-                return 1;
-            }
-            cur = expect;
-        }
-        if (cur == k) {
-            const double old = ld_l2(&tab[slot].val);
-            st_l2(&tab[slot].val, old + add);
-            return 0;
-        }
-        slot = (slot + 1 == cap) ? 0 : slot + 1;
-    }
-    return -1;
-}
-
 // ---------------------------------------------------------------- SCAN
-template <int BLOCK, bool IN_LDS>
+// Drains the residue table of one level (or one partition of it).  U slots per thread are
+// handled per round so that the indptr loads of all U nodes are in flight together.
+template <int BLOCK, bool IN_LDS, int U>
 __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
-                                           ResRec* resg, u32 cap, RsvRec* rsv, int* rlist,
+                                           ResRec* resg, u32 cap, int* log_key, double* log_val,
                                            PushEntry* push, double c, bool do_push,
                                            u64& st_push, u64& st_edges, u64& st_front)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    const u32 rsv_cap = (u32)p.rsv_cap;
-    for (u32 base = 0; base < cap; base += BLOCK) {
-        const u32 slot = base + tid;
-        int k = kEmpty;
-        double r = 0.0;
-        if (slot < cap) {
-            if (IN_LDS) {
-                k = lkeys[slot];
-                if (k != kEmpty) { r = lvals[slot]; lkeys[slot] = kEmpty; lvals[slot] = 0.0; }
-            } else {
-                k = ld_l2(&resg[slot].key);
-                if (k != kEmpty) {
-                    r = ld_l2(&resg[slot].val);
-                    st_l2(&resg[slot].key, kEmpty);
-                    st_l2(&resg[slot].val, 0.0);
+    for (u32 base = 0; base < cap; base += BLOCK * U) {
+        int k[U]; double r[U];
+        // (a) drain U slots
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32 slot = base + (u32)u * BLOCK + tid;
+            k[u] = kEmpty; r[u] = 0.0;
+            if (slot < cap) {
+                if (IN_LDS) {
+                    k[u] = lkeys[slot];
+                    if (k[u] != kEmpty) { r[u] = lvals[slot]; lkeys[slot] = kEmpty; lvals[slot] = 0.0; }
+                } else {
+                    k[u] = ld_l2(&resg[slot].key);
+                    r[u] = ld_l2(&resg[slot].val);
                 }
             }
         }
-        u32 n_new = 0, new_slot = 0, n_chunks = 0;
-        int e_start = 0, e_len = 0;
-        double e_share = 0.0;
-        if (k != kEmpty) {
-            ++st_front;
-            const int rc = rsv_add(rsv, rsv_cap, k, c * r, &new_slot);      // graph.h:90 / :109
-            if (rc > 0) n_new = 1;
-            else if (rc < 0) ctl->fail = 1;
-            // deg >= 1 everywhere => a node with r < rmax can neither push nor be dangling
-            if (do_push && (r >= p.rmax || !p.no_dangling)) {
-                const int s = p.indptr[k], e = p.indptr[k + 1];
-                const u32 deg = (u32)(e - s);                               // graph.h:43-45
-                if (deg == 0) {                                             // graph.h:91-93
-                    __hip_atomic_fetch_add(&ctl->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!IN_LDS) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32 slot = base + (u32)u * BLOCK + tid;
+                if (k[u] != kEmpty) { st_l2(&resg[slot].key, kEmpty); st_l2(&resg[slot].val, 0.0); }
+            }
+        }
+        // (b) issue the degree loads of the round
+        int ds[U], de[U]; bool want_deg[U]; u32 n_occ = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            want_deg[u] = false; ds[u] = 0; de[u] = 0;
+            if (k[u] != kEmpty) {
+                ++n_occ;
+                // deg >= 1 everywhere => a node with r < rmax can neither push nor be dangling
+                want_deg[u] = do_push && (r[u] >= p.rmax || !p.no_dangling);
+                if (want_deg[u]) { ds[u] = p.indptr[k[u]]; de[u] = p.indptr[k[u] + 1]; }   // graph.h:43-45
+            }
+        }
+        // (c) reserve log: one (node, coef*r) record per frontier node          graph.h:90 / :109
+        u32 li = wave_alloc(&ctl->log_count, n_occ, lane);
+        if (n_occ) {
+            if ((u64)li + n_occ <= p.log_cap) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (k[u] != kEmpty) { log_key[li] = k[u]; log_val[li] = c * r[u]; ++li; }
+            } else {
+                ctl->fail = 1;
+            }
+            st_front += n_occ;
+        }
+        // (d) push decisions
+        u32 n_chunks = 0, e_sum = 0;
+        double share[U]; int len[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            share[u] = 0.0; len[u] = 0;
+            if (want_deg[u]) {
+                const u32 deg = (u32)(de[u] - ds[u]);
+                if (deg == 0) {                                                      // graph.h:91-93
+                    __hip_atomic_fetch_add(&ctl->dangling, r[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&ctl->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (r >= p.rmax * (double)deg) {                     // graph.h:94
+                } else if (r[u] >= p.rmax * (double)deg) {                           // graph.h:94
                     ++st_push; st_edges += deg;
-                    e_share = r / (double)deg;                              // graph.h:95
-                    if (e_share != 0.0) {
-                        e_start = s; e_len = (int)deg;
-                        n_chunks = (deg + kSplitLen - 1) / kSplitLen;
+                    const double sh = r[u] / (double)deg;                            // graph.h:95
+                    if (sh != 0.0) {
+                        share[u] = sh; len[u] = (int)deg;
+                        n_chunks += (deg + kSplitLen - 1) / kSplitLen;
+                        e_sum += deg;
                     }
                 }
             }
         }
-        // wave-level compaction of both lists (prefix sums over the 64 lanes)
-        const u32 li = wave_alloc(&ctl->list_count, n_new, lane);
-        if (n_new) {
-            if (li < p.list_cap) rlist[li] = (int)new_slot; else ctl->fail = 1;
-        }
-        const u32 pi = wave_alloc(&ctl->n_push, n_chunks, lane);
+        // (e) wave-level compaction of the push list (prefix sums over the 64 lanes)
+        u32 pi = wave_alloc(&ctl->n_push, n_chunks, lane);
         if (n_chunks) {
-            __hip_atomic_fetch_add(&ctl->e_next, (u32)e_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&ctl->e_next, e_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((u64)pi + n_chunks <= p.push_cap) {
-                for (u32 j = 0; j < n_chunks; ++j) {
-                    PushEntry pe;
-                    pe.start = e_start + (int)j * kSplitLen;
-                    pe.len = min(kSplitLen, e_len - (int)j * kSplitLen);
-                    pe.share = e_share;
-                    push[pi + j] = pe;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    for (int off = 0; off < len[u]; off += kSplitLen) {
+                        PushEntry pe;
+                        pe.start = ds[u] + off;
+                        pe.len = min(kSplitLen, len[u] - off);
+                        pe.share = share[u];
+                        push[pi++] = pe;
+                    }
                 }
             } else {
                 ctl->fail = 1;
@@ -287,12 +310,16 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkey
 }
 
 // ---------------------------------------------------------------- EXPAND
-// G lanes (a power of two, 4..64) cooperate on one push-list entry: lanes read consecutive
-// column ids of the CSR range (coalesced) and add the share into the next residue table.
+// G lanes (a power of two, 4..64 ~ the mean range length) cooperate on one push-list entry;
+// groups stride over the list so that every wave has work even when the list is short.
+// Lanes read consecutive column ids of the CSR range (coalesced) and add the share into the
+// next residue table; two column ids per lane are in flight before the first table update.
+// With parts > 1 only targets of hash partition `part` are kept (the others belong to a
+// later pass over the same list).
 template <int BLOCK, bool IN_LDS>
 __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
                                              ResRec* resg, u32 cap, const PushEntry* push,
-                                             u32 n_push, int log2g)
+                                             u32 n_push, int log2g, u32 part, u32 parts)
 {
     const int tid = threadIdx.x;
     const int G = 1 << log2g;
@@ -303,13 +330,28 @@ __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lk
     for (u32 e = gid; e < n_push; e += n_groups) {
         const PushEntry pe = push[e];
         const int* nbr = p.indices + pe.start;
-        for (int j = gl; j < pe.len; j += G) {
-            const int v = nbr[j];                                           // graph.h:97
-            if (IN_LDS) ok &= res_add_lds(lkeys, lvals, cap, v, pe.share);  // graph.h:98
-            else        ok &= res_add_hbm(resg, cap, v, pe.share);
+        const int len = pe.len;
+        const double share = pe.share;
+        int j = gl;
+        for (; j + G < len; j += 2 * G) {
+            const int v0 = nbr[j];                                          // graph.h:97
+            const int v1 = nbr[j + G];
+            const bool m0 = parts == 1 || slot_of(hash_b((u32)v0), parts) == part;
+            const bool m1 = parts == 1 || slot_of(hash_b((u32)v1), parts) == part;
+            if (IN_LDS) { if (m0) ok &= res_add_lds(lkeys, lvals, cap, v0, share);  // graph.h:98
+                          if (m1) ok &= res_add_lds(lkeys, lvals, cap, v1, share); }
+            else        { if (m0) ok &= res_add_hbm(resg, cap, v0, share);
+                          if (m1) ok &= res_add_hbm(resg, cap, v1, share); }
+        }
+        if (j < len) {
+            const int v0 = nbr[j];
+            if (parts == 1 || slot_of(hash_b((u32)v0), parts) == part) {
+                if (IN_LDS) ok &= res_add_lds(lkeys, lvals, cap, v0, share);
+                else        ok &= res_add_hbm(resg, cap, v0, share);
+            }
         }
     }
-    if (!ok) ctl->fail = 1;
+    if (!ok) { if (IN_LDS) ctl->ovf = 1; else ctl->fail = 1; }
 }
 
 // ---------------------------------------------------------------- TOP-K
@@ -320,114 +362,194 @@ __device__ __forceinline__ u128 composite(const Cand& c) {
     return ((u128)c.bits << 32) | (u128)(u32)(~(u32)c.key);
 }
 
+// One wave finds, in a 4096-bin histogram, the bin holding the `want`-th largest entry.
+__device__ __forceinline__ void topk_pick_bin(Ctl* ctl, const u32* hist, u32 want, int lane) {
+    // chunk sums: lane owns bins [64*lane, 64*lane+64); skewed reads avoid bank conflicts
+    u32 csum = 0;
+    for (int j = 0; j < 64; ++j) csum += hist[64 * lane + ((j + lane) & 63)];
+    const u32 csuf = wave_suffix_scan(csum, lane);              // bins >= 64*lane
+    const u64 cm = __ballot(csuf >= want);
+    const int cl = __popcll(cm) - 1;                            // chunk holding the want-th largest
+    const u32 above_c = __shfl(csuf, cl) - __shfl(csum, cl);    // bins above that chunk
+    const u32 b = hist[64 * cl + lane];
+    const u32 bsuf = wave_suffix_scan(b, lane) + above_c;       // bins >= this bin
+    const u64 bm = __ballot(bsuf >= want);
+    const int bl = __popcll(bm) - 1;
+    if (lane == bl) {
+        ctl->tk_bin = (u32)(64 * cl + bl);
+        ctl->tk_above = bsuf - b;
+        ctl->tk_count = b;
+    }
+}
+
+// RESERVE + TOP-K of one row (graph.h:111-126).  `scratch` is the whole LDS table region:
+//   hist[4096] u32 | sel[K] | tie[kBucketCap] | agg = { vals f64[CA], keys i32[CA] }  (re-used as big[] of Cand)
+// 1. The reserve log is summed per node in the LDS table `agg` (one partition of the keys at
+//    a time when the log is long); each occupied slot is a node of the reserve map.  Values
+//    > 0 (graph.h:121) become candidates: written to `cand` and counted in the histogram of
+//    their first radix digit (sign+exponent).
+// 2. MSD radix select with 12-bit digits; as soon as the bucket holding the K-th value fits
+//    `big`, it is compacted into LDS and the remaining passes never touch HBM again.
 template <int BLOCK>
-__device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned char* scratch,
-                                         RsvRec* rsv, const int* rlist, Cand* cand,
-                                         long long row, int seed, u64& st_filled)
+__device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned char* scratch, u32 scratch_bytes,
+                                         const int* log_key, const double* log_val, Cand* cand,
+                                         long long row, int seed, u64& st_filled, u64& st_support)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32*  hist   = (u32*)scratch;                                    // [kTopkBins]
-    Cand* sel    = (Cand*)(scratch + kTopkBins * sizeof(u32));       // [K]
-    Cand* bucket = sel + p.K;                                        // [kBucketCap]
-    const u32 n = ctl->list_count;
+    u32*  hist = (u32*)scratch;                                      // [kTopkBins]
+    Cand* sel  = (Cand*)(scratch + kTopkBins * sizeof(u32));         // [K]
+    Cand* tie  = sel + p.K;                                          // [kBucketCap]
+    unsigned char* region = (unsigned char*)(tie + kBucketCap);
+    const u32 region_bytes = scratch_bytes - (u32)(region - scratch);
+    const u32 CA = region_bytes / 12;
+    double* avals = (double*)region;
+    int* akeys = (int*)(region + 8 * (size_t)CA);
+    Cand* big = (Cand*)region;
+    const u32 big_cap = region_bytes / (u32)sizeof(Cand);
+    const u32 n_log = ctl->log_count;
     const u32 K = (u32)p.K;
 
-    // pass 0: gather (column, value) of the reserve map, clean the table, keep value > 0
-    for (u32 base = 0; base < n; base += BLOCK) {
-        const u32 i = base + tid;
-        u32 keep = 0;
-        Cand c; c.bits = 0; c.key = 0; c.pad = 0;
-        if (i < n) {
-            const u32 slot = (u32)rlist[i];
-            c.key = ld_l2(&rsv[slot].key);
-            const double v = ld_l2(&rsv[slot].val);
-            st_l2(&rsv[slot].key, kEmpty);
-            if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); keep = 1; }    // graph.h:121
+    // ---- 1. aggregate the log -> candidates + first histogram
+    u32 parts = 1;
+    if ((u64)n_log * 4 > (u64)CA * 3) parts = (u32)(((u64)n_log * 2 + CA - 1) / CA);   // ~0.5 load per partition
+    u64 support = 0;
+    for (;;) {
+        for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+        if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
+        support = 0;
+        bool overflow = false;
+        for (u32 part = 0; part < parts; ++part) {
+            for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
+            __syncthreads();
+            bool ok = true;
+            for (u32 base = 0; base < n_log; base += 2 * BLOCK) {
+                const u32 i0 = base + tid, i1 = base + BLOCK + tid;
+                int k0 = kEmpty, k1 = kEmpty; double v0 = 0.0, v1 = 0.0;
+                if (i0 < n_log) { k0 = log_key[i0]; v0 = log_val[i0]; }
+                if (i1 < n_log) { k1 = log_key[i1]; v1 = log_val[i1]; }
+                if (k0 != kEmpty && (parts == 1 || slot_of(hash_b((u32)k0), parts) == part))
+                    ok &= res_add_lds(akeys, avals, CA, k0, v0);
+                if (k1 != kEmpty && (parts == 1 || slot_of(hash_b((u32)k1), parts) == part))
+                    ok &= res_add_lds(akeys, avals, CA, k1, v1);
+            }
+            if (!ok) ctl->ovf = 1;
+            __syncthreads();
+            if (ctl->ovf) { overflow = true; break; }
+            for (u32 base = 0; base < CA; base += BLOCK) {
+                const u32 slot = base + tid;
+                u32 keep = 0;
+                Cand c; c.bits = 0; c.key = 0; c.pad = 0;
+                if (slot < CA) {
+                    const int k = akeys[slot];
+                    if (k != kEmpty) {
+                        ++support;                                                   // graph.h:111 res.size()
+                        const double v = avals[slot];
+                        if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); c.key = k; keep = 1; }   // graph.h:121
+                    }
+                }
+                const u32 ci = wave_alloc(&ctl->n_cand, keep, lane);
+                if (keep) {
+                    if (ci < p.cand_cap) cand[ci] = c; else ctl->fail = 1;
+                    __hip_atomic_fetch_add(&hist[(u32)(c.bits >> 52)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __syncthreads();
         }
-        const u32 ci = wave_alloc(&ctl->n_cand, keep, lane);
-        if (keep) cand[ci] = c;
+        if (!overflow) break;
+        parts *= 2;                                   // a partition did not fit: split finer and redo
+        __syncthreads();
     }
-    __syncthreads();
+    st_support += support;
     const u32 m = ctl->n_cand;
     const u32 need = m < K ? m : K;                                   // graph.h:113
-    if (need == 0) {
+    if (need == 0 || ctl->fail) {
         if (tid == 0 && p.out_filled) p.out_filled[row] = 0;
         return;
     }
 
+    // ---- 2. select
     if (m <= K) {
         for (u32 i = tid; i < m; i += BLOCK) sel[i] = cand[i];
         __syncthreads();
     } else {
-        // MSD radix select on the composite, 12 bits per pass, early exit on a small bucket
+        const Cand* cur = cand;     // current candidate array: HBM, or `big` in LDS after compaction
+        u32 cur_n = m;
+        bool compacted = false;
         u128 prefix = 0;
         u32 want = K;               // how many must still come from the current bucket
         int depth = 0;              // digits fixed so far
-        bool take_all_bucket = false;
+        bool take_all = false;
         for (;;) {
-            for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
-            __syncthreads();
-            const int shift = 96 - 12 * (depth + 1);
-            for (u32 i = tid; i < m; i += BLOCK) {
-                const u128 comp = composite(cand[i]);
-                if (depth == 0 || (comp >> (shift + 12)) == prefix)
-                    __hip_atomic_fetch_add(&hist[(u32)(comp >> shift) & (kTopkBins - 1)], 1u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            __syncthreads();
-            if (wave == 0) {
-                // chunk sums: lane owns bins [64*lane, 64*lane+64); skewed reads avoid bank conflicts
-                u32 csum = 0;
-                for (int j = 0; j < 64; ++j) csum += hist[64 * lane + ((j + lane) & 63)];
-                const u32 csuf = wave_suffix_scan(csum, lane);              // bins >= 64*lane
-                const u64 cm = __ballot(csuf >= want);
-                const int cl = __popcll(cm) - 1;                            // chunk holding the want-th largest
-                const u32 above_c = __shfl(csuf, cl) - __shfl(csum, cl);    // bins above that chunk
-                const u32 b = hist[64 * cl + lane];
-                const u32 bsuf = wave_suffix_scan(b, lane) + above_c;       // bins >= this bin
-                const u64 bm = __ballot(bsuf >= want);
-                const int bl = __popcll(bm) - 1;
-                if (lane == bl) {
-                    ctl->tk_bin = (u32)(64 * cl + bl);
-                    ctl->tk_above = bsuf - b;
-                    ctl->tk_count = b;
+            if (depth > 0) {
+                for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+                __syncthreads();
+                const int shift = 96 - 12 * (depth + 1);
+                for (u32 i = tid; i < cur_n; i += BLOCK) {
+                    const u128 comp = composite(cur[i]);
+                    if ((comp >> (shift + 12)) == prefix)
+                        __hip_atomic_fetch_add(&hist[(u32)(comp >> shift) & (kTopkBins - 1)], 1u,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                __syncthreads();
             }
+            if (wave == 0) topk_pick_bin(ctl, hist, want, lane);
             __syncthreads();
             prefix = (prefix << 12) | (u128)ctl->tk_bin;
             want -= ctl->tk_above;
             const u32 cnt = ctl->tk_count;
             ++depth;
             __syncthreads();
-            if (cnt == want) { take_all_bucket = true; break; }
+            if (cnt == want) { take_all = true; break; }
             if (cnt <= (u32)kBucketCap || depth == 8) break;
+            if (!compacted && cnt <= big_cap) {
+                // move everything strictly above the prefix to `sel`, the bucket itself to LDS
+                const int sh = 96 - 12 * depth;
+                for (u32 base = 0; base < cur_n; base += BLOCK) {
+                    const u32 i = base + tid;
+                    u32 is_sel = 0, is_b = 0;
+                    Cand c; c.bits = 0; c.key = 0; c.pad = 0;
+                    if (i < cur_n) {
+                        c = cur[i];
+                        const u128 pre = composite(c) >> sh;
+                        is_sel = pre > prefix; is_b = pre == prefix;
+                    }
+                    const u32 si = wave_alloc(&ctl->n_sel, is_sel, lane);
+                    if (is_sel) sel[si] = c;
+                    const u32 bi = wave_alloc(&ctl->n_bucket, is_b, lane);
+                    if (is_b) big[bi] = c;
+                }
+                __syncthreads();
+                cur = big; cur_n = cnt; compacted = true;
+                if (tid == 0) ctl->n_bucket = 0;
+                __syncthreads();
+            }
         }
         // collect: strictly above the prefix -> selected; equal to the prefix -> tie bucket
         const int shift = 96 - 12 * depth;
-        for (u32 base = 0; base < m; base += BLOCK) {
+        for (u32 base = 0; base < cur_n; base += BLOCK) {
             const u32 i = base + tid;
             u32 is_sel = 0, is_b = 0;
             Cand c; c.bits = 0; c.key = 0; c.pad = 0;
-            if (i < m) {
-                c = cand[i];
+            if (i < cur_n) {
+                c = cur[i];
                 const u128 pre = composite(c) >> shift;
-                if (pre > prefix || (take_all_bucket && pre == prefix)) is_sel = 1;
+                if (pre > prefix || (take_all && pre == prefix)) is_sel = 1;
                 else if (pre == prefix) is_b = 1;
             }
             const u32 si = wave_alloc(&ctl->n_sel, is_sel, lane);
             if (is_sel) sel[si] = c;
             const u32 bi = wave_alloc(&ctl->n_bucket, is_b, lane);
-            if (is_b && bi < (u32)kBucketCap) bucket[bi] = c;
+            if (is_b && bi < (u32)kBucketCap) tie[bi] = c;
         }
         __syncthreads();
-        if (!take_all_bucket) {
+        if (!take_all) {
             const u32 nb = min(ctl->n_bucket, (u32)kBucketCap);
             const u32 n_sel0 = ctl->n_sel;                     // == K - want
             for (u32 i = tid; i < nb; i += BLOCK) {
-                const u128 mine = composite(bucket[i]);
+                const u128 mine = composite(tie[i]);
                 u32 rank = 0;
-                for (u32 j = 0; j < nb; ++j) rank += composite(bucket[j]) > mine ? 1u : 0u;
-                if (rank < want) sel[n_sel0 + rank] = bucket[i];
+                for (u32 j = 0; j < nb; ++j) rank += composite(tie[j]) > mine ? 1u : 0u;
+                if (rank < want) sel[n_sel0 + rank] = tie[i];
             }
             __syncthreads();
         }
@@ -461,15 +583,19 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
     const u32 C = p.lds_slots;
 
     const size_t wg = blockIdx.x;
-    PushEntry* push = p.push + wg * p.push_cap;
-    ResRec* resg    = p.resg + wg * p.resg_cap;
-    RsvRec* rsv     = p.rsv + wg * p.rsv_cap;
-    int* rlist      = p.rsv_list + wg * p.list_cap;
-    Cand* cand      = p.cand + wg * p.list_cap;
+    PushEntry* push2 = p.push + wg * 2 * p.push_cap;
+    ResRec* resg     = p.resg + wg * p.resg_cap;
+    int* log_key     = p.log_key + wg * p.log_cap;
+    double* log_val  = p.log_val + wg * p.log_cap;
+    Cand* cand       = p.cand + wg * p.cand_cap;
 
     for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
     u64 st_push = 0, st_edges = 0, st_front = 0, st_filled = 0, st_support = 0,
         st_lds = 0, st_glb = 0, st_failed = 0;
+    u64 tk_scan = 0, tk_expand = 0, tk_topk = 0, tk_total = 0, t0 = 0, t1 = 0, t2 = 0, tk_begin = 0;
+    u64 tk_scan_hbm = 0, tk_expand_hbm = 0; (void)tk_scan_hbm; (void)tk_expand_hbm;
+    (void)tk_scan; (void)tk_expand; (void)tk_topk; (void)tk_total; (void)t0; (void)t1; (void)t2; (void)tk_begin;
+    GP_STAMP(tk_begin);
     const int L = p.n_coef - 1;
 
     for (;;) {
@@ -477,7 +603,7 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
         if (tid == 0) {
             ctl->row = (long long)__hip_atomic_fetch_add(&p.counters[kQueue], 1ull, __ATOMIC_RELAXED,
                                                          __HIP_MEMORY_SCOPE_AGENT);
-            ctl->list_count = 0; ctl->n_cand = 0; ctl->fail = 0;
+            ctl->log_count = 0; ctl->n_cand = 0; ctl->fail = 0; ctl->ovf = 0;
             ctl->n_sel = 0; ctl->n_bucket = 0;
         }
         __syncthreads();
@@ -489,69 +615,117 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
             continue;
         }
 
-        // level-0 frontier = { seed : 1.0 }                                   graph.h:81
-        bool in_lds = !p.force_global;
-        u32 cap = in_lds ? min(C, kMinCap) : (u32)min((u64)kMinCap, p.resg_cap);
-        if (tid == 0) {
-            const u32 s0 = slot_of(hash_a((u32)seed), cap);
-            if (in_lds) { lkeys[s0] = seed; lvals[s0] = 1.0; }
-            else { st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
-        }
-        __syncthreads();
+        // state of the level about to be produced: its push list (built by the previous SCAN)
+        u32 n_push_cur = 0, e_cur = 0;
+        double dang_cur = 0.0;
+        bool has_dang_cur = false;
+        int cur = 0;
 
-        for (int lvl = 0;; ++lvl) {
-            if (tid == 0) { ctl->n_push = 0; ctl->e_next = 0; ctl->dangling = 0.0; ctl->n_dangling = 0; }
-            __syncthreads();
+        for (int lvl = 0; lvl <= L; ++lvl) {
             const double c = p.coef[lvl];
             const bool do_push = lvl < L;                                     // graph.h:83 vs :104
-            if (in_lds) scan_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, rsv, rlist, push, c, do_push, st_push, st_edges, st_front);
-            else        scan_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, rsv, rlist, push, c, do_push, st_push, st_edges, st_front);
-            if (tid == 0) { if (in_lds) ++st_lds; else ++st_glb; }
-            __syncthreads();
-            if (!do_push || ctl->fail) break;
-            const u32 n_push = ctl->n_push;
-            const double dang = ctl->dangling;
-            const bool has_dang = ctl->n_dangling != 0;
-            // distinct targets of the next level <= min(edges (+ the seed), N)
-            const u64 need = min((u64)ctl->e_next + (has_dang ? 1 : 0), (u64)p.n_nodes);
-            if (need == 0) break;                       // the frontier died: later levels add nothing
-            // next level's table: LDS iff it is guaranteed to fit (distinct targets <= edges)
-            in_lds = !p.force_global && need * 10 <= (u64)C * 7;
+            // distinct targets of this level <= min(edges (+ the seed), N)
+            u64 need = 1;
+            if (lvl > 0) {
+                need = min((u64)e_cur + (has_dang_cur ? 1 : 0), (u64)p.n_nodes);
+                if (need == 0) break;                   // the frontier died: later levels add nothing
+            }
+            // placement of the level's residue table
+            bool in_lds = !p.force_global;
+            u32 parts = 1, cap = 0;
             if (in_lds) {
-                cap = (u32)min((u64)C, max((u64)kMinCap, 4 * need));
-            } else {
-                if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; __syncthreads(); break; }
-                cap = (u32)min(p.resg_cap, max((u64)kMinCap, 2 * need));
+                if (need * 4 <= (u64)C * 3) {
+                    cap = (u32)min((u64)C, max((u64)kMinCap, 4 * need));
+                } else {
+                    parts = (u32)((need * 20 + (u64)C * 11 - 1) / ((u64)C * 11));      // ~0.55 load per partition
+                    cap = C;
+                    if (parts > kMaxParts) in_lds = false;
+                }
             }
             int log2g = 2;                               // lanes per entry ~ mean range length
-            if (n_push) { const u32 avg = ctl->e_next / n_push; while (log2g < 6 && (1u << log2g) < avg) ++log2g; }
-            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push, n_push, log2g);
-            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push, n_push, log2g);
-            if (tid == 0 && has_dang) {                                        // graph.h:92
-                const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed, dang)
-                                       : res_add_hbm(resg, cap, seed, dang);
-                if (!ok) ctl->fail = 1;
+            if (n_push_cur) { const u32 avg = e_cur / n_push_cur; while (log2g < 6 && (1u << log2g) < avg) ++log2g; }
+            PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
+            PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
+            const u64 snap_push = st_push, snap_edges = st_edges, snap_front = st_front;
+            const u32 snap_log = ctl->log_count;
+
+            for (;;) {      // normally one trip; repeats only if an LDS partition overflowed
+                if (!in_lds) {
+                    parts = 1;
+                    if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; }
+                    cap = (u32)min(p.resg_cap, max((u64)kMinCap, 2 * need));
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    ctl->n_push = 0; ctl->e_next = 0; ctl->dangling = 0.0; ctl->n_dangling = 0;
+                    ctl->ovf = 0; ctl->log_count = snap_log;
+                }
+                __syncthreads();
+                bool overflow = false;
+                if (!ctl->fail) {
+                    for (u32 part = 0; part < parts; ++part) {
+                        GP_STAMP(t0);
+                        if (lvl == 0) {                                      // frontier { seed : 1.0 }   graph.h:81
+                            if (tid == 0) {
+                                const u32 s0 = slot_of(hash_a((u32)seed), cap);
+                                if (in_lds) { lkeys[s0] = seed; lvals[s0] = 1.0; }
+                                else { st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
+                            }
+                        } else {
+                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, log2g, part, parts);
+                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, log2g, part, parts);
+                            if (tid == 0 && has_dang_cur &&
+                                (parts == 1 || slot_of(hash_b((u32)seed), parts) == part)) {        // graph.h:92
+                                const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed, dang_cur)
+                                                       : res_add_hbm(resg, cap, seed, dang_cur);
+                                if (!ok) { if (in_lds) ctl->ovf = 1; else ctl->fail = 1; }
+                            }
+                        }
+                        __syncthreads();
+                        GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1); if (!in_lds) GP_ACCUM(tk_expand_hbm, t0, t1);
+                        if (ctl->ovf || ctl->fail) { overflow = ctl->ovf != 0; break; }
+                        if (in_lds) scan_level<BLOCK, true,  4>(p, ctl, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
+                        else        scan_level<BLOCK, false, 4>(p, ctl, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
+                        __syncthreads();
+                        GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
+                        if (ctl->fail) break;
+                    }
+                }
+                if (ctl->fail || !overflow) break;
+                // an LDS partition overflowed: wipe the table, forget this level's output, split finer
+                for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+                st_push = snap_push; st_edges = snap_edges; st_front = snap_front;
+                parts *= 2;
+                if (parts > kMaxParts) in_lds = false;
             }
-            __syncthreads();
-            if (ctl->fail) break;
+            if (tid == 0) { if (in_lds) ++st_lds; else ++st_glb; }
+            if (ctl->fail || !do_push) break;
+            n_push_cur = ctl->n_push; e_cur = ctl->e_next;
+            dang_cur = ctl->dangling; has_dang_cur = ctl->n_dangling != 0;
+            cur ^= 1;
+            __syncthreads();                    // everyone has read the counters before they are reset
         }
         __syncthreads();
         if (ctl->fail) {
-            // Leave the row unwritten and report it; tables may be dirty -> host re-initialises.
+            // Leave the row unwritten and report it (GP_ERR_OVERFLOW).  Restore clean tables so
+            // that later rows of this workgroup are unaffected.
             if (tid == 0) { ++st_failed; if (p.out_filled) p.out_filled[row] = 0; }
-            // best-effort clean-up so that later rows of this workgroup are not corrupted
             for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+            for (u64 i = tid; i < p.resg_cap; i += BLOCK) { st_l2(&resg[i].key, kEmpty); st_l2(&resg[i].val, 0.0); }
             continue;
         }
-        if (tid == 0) st_support += ctl->list_count;
-        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, rsv, rlist, cand, row, seed, st_filled);
+        GP_STAMP(t0);
+        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, st_filled, st_support);
         __syncthreads();
+        if (ctl->fail && tid == 0) ++st_failed;
+        GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);
         // top-K used the table region as scratch: restore the empty LDS table
         for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
     }
 
     // flush statistics: one atomic per counter per workgroup
     st_push = wave_sum64(st_push); st_edges = wave_sum64(st_edges); st_front = wave_sum64(st_front);
+    st_support = wave_sum64(st_support);
     __syncthreads();
     u64* red = (u64*)(smem + kCtlBytes);
     if (tid < 8) red[tid] = 0;
@@ -560,40 +734,37 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
         __hip_atomic_fetch_add(&red[0], st_push, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&red[1], st_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&red[2], st_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&red[3], st_support, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_fetch_add(&p.counters[kPushes], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kEdges], red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kFrontier], red[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kSupport], red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kFilled], st_filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kSupport], st_support, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kLdsLevels], st_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kGlobalLevels], st_glb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kFailedRows], st_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GP_DIAG
+        tk_total = wall_clock64() - tk_begin;
+        __hip_atomic_fetch_add(&p.counters[kTicksScan], tk_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kTicksExpand], tk_expand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kTicksTopk], tk_topk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kTicksTotal], tk_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kTicksScanHbm], tk_scan_hbm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kTicksExpandHbm], tk_expand_hbm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
 }
 
-// Fills the per-workgroup HBM tables with empty records (a byte memset cannot: val must be 0).
-__global__ void __launch_bounds__(256) init_tables_kernel(ResRec* resg, u64 n_res, RsvRec* rsv, u64 n_rsv)
+// Fills the per-workgroup HBM residue tables with empty records (a byte memset cannot: val must be 0).
+__global__ void __launch_bounds__(256) init_tables_kernel(ResRec* resg, u64 n_res)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_res; i += stride) {
         ResRec r; r.key = kEmpty; r.pad = 0; r.val = 0.0; resg[i] = r;
     }
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_rsv; i += stride) {
-        RsvRec r; r.key = kEmpty; r.pad = 0; r.val = 0.0; rsv[i] = r;
-    }
-}
-
-// Minimum of indptr differences == 0 ?  (sets *flag to 1 if some node has degree 0)
-__global__ void __launch_bounds__(256) dangling_probe_kernel(const int* indptr, long long n, int* flag)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    int found = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        found |= (indptr[i + 1] == indptr[i]);
-    if (found) *flag = 1;
 }
 
 }  // namespace gp

@@ -59,6 +59,10 @@ typedef struct gp_stats {
     int32_t lds_bytes;       /* dynamic LDS per workgroup                                        */
     int32_t lds_slots;       /* residue-table slots that fit in that LDS                         */
     int64_t workspace_bytes; /* HBM scratch held for this configuration                          */
+    /* Filled only by the diagnostic build (libgrandplus_diag.so, -DGP_DIAG): 100 MHz ticks
+     * spent per phase, summed over workgroups.  Always 0 in the product library. */
+    int64_t diag_ticks_scan, diag_ticks_expand, diag_ticks_topk, diag_ticks_total;
+    int64_t diag_ticks_scan_hbm, diag_ticks_expand_hbm;   /* the part of scan/expand spent on HBM-table levels */
 } gp_stats;
 
 /* ABI / build information. */

@@ -224,6 +224,9 @@ def main():
         if stats.get("diag_ticks_total"):
             tot = stats["diag_ticks_total"]
             line["detail"]["diag_phase_share"] = {k: round(stats[f"diag_ticks_{k}"] / tot, 3) for k in ("scan", "expand", "topk", "scan_hbm", "expand_hbm")}
+            names = ["agg_init", "agg_insert", "agg_scan", "sel_hist", "sel_pick", "sel_compact", "sel_collect", "final"]
+            line["detail"]["diag_topk_sub_share"] = {n: round(stats["diag_sub"][i] / tot, 3) for i, n in enumerate(names)}
+            line["detail"]["diag_counts_per_row"] = {"agg_parts": round(stats["diag_sub"][8] / stats["rows"], 2), "sel_passes_hbm": round(stats["diag_sub"][9] / stats["rows"], 2), "sel_passes_lds": round(stats["diag_sub"][10] / stats["rows"], 2)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(indptr, indices, all_seeds[args.warmup * S_step:], recipe, args.cpu_budget_s)
             line["cpu_baseline"] = cb

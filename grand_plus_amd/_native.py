@@ -39,10 +39,13 @@ class GpStats(ctypes.Structure):
         ("diag_ticks_scan", ctypes.c_int64), ("diag_ticks_expand", ctypes.c_int64),
         ("diag_ticks_topk", ctypes.c_int64), ("diag_ticks_total", ctypes.c_int64),
         ("diag_ticks_scan_hbm", ctypes.c_int64), ("diag_ticks_expand_hbm", ctypes.c_int64),
+        ("diag_sub", ctypes.c_int64 * 16),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["diag_sub"] = list(self.diag_sub)
+        return d
 
 
 _LIB = None

@@ -309,7 +309,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
 
     // LDS table geometry: 12 B per slot after the control block; top-K scratch must fit in it
     const int lds_bytes = g->lds_bytes;
-    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12);
+    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~3u;     // bucketed probing: multiple of 4
     if ((size_t)lds_slots * 12 < kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap)
         return fail(GP_ERR_INVALID_ARG, "lds_bytes too small for K = %d", K);
 
@@ -411,6 +411,7 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     s.diag_ticks_total = (int64_t)g->h_counters[kTicksTotal];
     s.diag_ticks_scan_hbm = (int64_t)g->h_counters[kTicksScanHbm];
     s.diag_ticks_expand_hbm = (int64_t)g->h_counters[kTicksExpandHbm];
+    for (int i = 0; i < 16; ++i) s.diag_sub[i] = (int64_t)g->h_counters[kDiag0 + i];
     if (out) *out = s;
     if (s.failed_rows) {
         g->ws.dirty = true;

@@ -48,13 +48,15 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int    kEmpty      = -1;
-constexpr int    kSplitLen   = 256;     // a CSR range longer than this is split into chunks
+constexpr int    kSplitLen   = 256;     // a long CSR range is split into chunks of this many columns
+constexpr int    kLongLen    = 64;      // ranges longer than this are expanded by a whole wave
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
 constexpr int    kCtlBytes   = 256;     // control block at the start of dynamic LDS
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 8;       // most hash partitions a level is expanded in before using the HBM table
-constexpr u32    kMaxProbe   = 1024;    // an LDS insert that probes this far reports overflow (recoverable)
+constexpr u32    kMaxProbe   = 16;      // an LDS insert that walks this many 4-key buckets reports overflow
+                                        // (recoverable: the level / aggregation is redone in more partitions)
 
 struct PushEntry { int start; int len; double share; };  // 16 B
 struct ResRec    { int key;   int pad; double val; };    // 16 B  residue table record (HBM)
@@ -65,7 +67,9 @@ struct Ctl {
     long long row;        // row index pulled from the queue
     double dangling;      // mass returned to the seed by dangling nodes this level
     u32 n_dangling;       // how many dangling nodes were drained this level
-    u32 n_push;           // push-list entries of this level
+    u32 n_push;           // SHORT push-list entries of this level (range length <= kLongLen), growing from the front
+    u32 n_long;           // LONG entries (chunks of <= kSplitLen), growing from the back of the same buffer
+    u32 e_short;          // edges covered by the short entries
     u32 e_next;           // sum of their lengths = edges the next EXPAND will traverse
     u32 log_count;        // reserve-log records so far
     u32 n_cand;           // top-K candidates (value > 0)
@@ -80,7 +84,8 @@ struct Ctl {
 
 enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
                kGlobalLevels, kFailedRows,
-               kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
+               kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
+               kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
                kNumCounters };
 
 // Phase stamps exist only in the diagnostic build (-DGP_DIAG): thread 0 reads the constant
@@ -88,9 +93,23 @@ enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLe
 #ifdef GP_DIAG
 #define GP_STAMP(var) do { if (threadIdx.x == 0) var = wall_clock64(); } while (0)
 #define GP_ACCUM(acc, t0, t1) do { if (threadIdx.x == 0) acc += (t1) - (t0); } while (0)
+// sub-phase stamp: adds the time since the previous GP_SUB/GP_SUB_BEGIN to diag slot `i` (thread 0)
+#define GP_SUB_BEGIN() do { if (threadIdx.x == 0) gp_sub_t = wall_clock64(); } while (0)
+#define GP_SUB(i) do { if (threadIdx.x == 0) { const u64 n_ = wall_clock64(); gp_sub_acc[i] += n_ - gp_sub_t; gp_sub_t = n_; } } while (0)
+#define GP_SUB_COUNT(i, n) do { if (threadIdx.x == 0) gp_sub_acc[i] += (n); } while (0)
 #else
 #define GP_STAMP(var) do { } while (0)
 #define GP_ACCUM(acc, t0, t1) do { } while (0)
+#define GP_SUB_BEGIN() do { } while (0)
+#define GP_SUB(i) do { } while (0)
+#define GP_SUB_COUNT(i, n) do { } while (0)
+#endif
+#ifdef GP_DIAG
+#define GP_SUB_PARAMS , u64& gp_sub_t, u64 (&gp_sub_acc)[16]
+#define GP_SUB_ARGS , gp_sub_t, gp_sub_acc
+#else
+#define GP_SUB_PARAMS
+#define GP_SUB_ARGS
 #endif
 
 struct KParams {
@@ -163,25 +182,71 @@ __device__ __forceinline__ u32 wave_alloc(u32* lds_counter, u32 n, int lane) {
     return base + incl - n;
 }
 
+// Flag form: each lane has 0 or 1 item.  One ballot, one popcount, one mbcnt pair -- the
+// "wavefront ballot / prefix-sum" compaction with no cross-lane data movement at all.
+__device__ __forceinline__ u32 lane_prefix(u64 mask) {           // set bits below my lane
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+__device__ __forceinline__ u32 wave_alloc1(u32* lds_counter, bool flag, int lane) {
+    const u64 m = __ballot(flag);
+    if (m == 0) return 0;                                         // wave-uniform
+    u32 base = 0;
+    if (lane == 0)
+        base = __hip_atomic_fetch_add(lds_counter, (u32)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+    return base + lane_prefix(m);
+}
+// U flags per lane (item u of every lane precedes item u+1 of any lane inside the wave's block).
+template <int U>
+__device__ __forceinline__ void wave_alloc_flags(u32* lds_counter, const bool (&flag)[U], u32 (&idx)[U], int lane) {
+    u64 m[U]; u32 total = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { m[u] = __ballot(flag[u]); total += (u32)__popcll(m[u]); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) idx[u] = 0;
+    if (total == 0) return;                                       // wave-uniform
+    u32 base = 0;
+    if (lane == 0)
+        base = __hip_atomic_fetch_add(lds_counter, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + lane_prefix(m[u]); base += (u32)__popcll(m[u]); }
+}
+
 // ---------------------------------------------------------------- residue tables
+// LDS table insert-or-add.  The table is probed in BUCKETS of 4 keys (two 64-bit LDS loads):
+// a wave pays the maximum probe count over its 64 lanes, and with one key per probe that
+// maximum is tens of iterations at load 0.6-0.7; with 4 keys per probe it is 1-3.
+// `cap` must be a multiple of 4 and `keys` 16-byte aligned.  Keys never revert to EMPTY
+// while inserts are running, which is what makes "claim the first EMPTY slot, re-read the
+// bucket if the claim lost" produce at most one slot per key.
 __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {
-    u32 slot = slot_of(hash_a((u32)k), cap);
-    const u32 max_probe = cap < kMaxProbe ? cap : kMaxProbe;
-    for (u32 probe = 0; probe < max_probe; ++probe) {
-        int cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (cur == kEmpty) {
-            int expect = kEmpty;
-            if (__hip_atomic_compare_exchange_strong(&keys[slot], &expect, k, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                cur = k;
-            else
-                cur = expect;
+    const u32 nb = cap >> 2;
+    u32 b = slot_of(hash_a((u32)k), nb);
+    const u32 max_probe = nb < kMaxProbe ? nb : kMaxProbe;
+    const u64* keys64 = (const u64*)keys;
+    for (u32 probe = 0; probe < max_probe;) {
+        const u64 lo = __hip_atomic_load(&keys64[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u64 hi = __hip_atomic_load(&keys64[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int k0 = (int)(u32)lo, k1 = (int)(u32)(lo >> 32), k2 = (int)(u32)hi, k3 = (int)(u32)(hi >> 32);
+        int idx = k0 == k ? 0 : k1 == k ? 1 : k2 == k ? 2 : k3 == k ? 3 : -1;
+        if (idx < 0) {
+            const int e = k0 == kEmpty ? 0 : k1 == kEmpty ? 1 : k2 == kEmpty ? 2 : k3 == kEmpty ? 3 : -1;
+            if (e >= 0) {
+                int expect = kEmpty;
+                if (__hip_atomic_compare_exchange_strong(&keys[4 * b + e], &expect, k, __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || expect == k)
+                    idx = e;
+                else
+                    continue;               // another key claimed that slot first: look at the bucket again
+            }
         }
-        if (cur == k) {
-            __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (idx >= 0) {
+            __hip_atomic_fetch_add(&vals[4 * b + idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return true;
         }
-        slot = (slot + 1 == cap) ? 0 : slot + 1;
+        b = (b + 1 == nb) ? 0 : b + 1;
+        ++probe;
     }
     return false;
 }
@@ -217,8 +282,10 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkey
                                            u64& st_push, u64& st_edges, u64& st_front)
 {
     const int tid = threadIdx.x, lane = tid & 63;
+    const u32 wave_first = (u32)(tid & ~63);
     for (u32 base = 0; base < cap; base += BLOCK * U) {
-        int k[U]; double r[U];
+        if (base + wave_first >= cap) break;            // wave-uniform: nothing left for this wave
+        int k[U]; double r[U]; bool occ[U];
         // (a) drain U slots
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -233,44 +300,42 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkey
                     r[u] = ld_l2(&resg[slot].val);
                 }
             }
+            occ[u] = k[u] != kEmpty;
         }
         if (!IN_LDS) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const u32 slot = base + (u32)u * BLOCK + tid;
-                if (k[u] != kEmpty) { st_l2(&resg[slot].key, kEmpty); st_l2(&resg[slot].val, 0.0); }
+                if (occ[u]) { st_l2(&resg[slot].key, kEmpty); st_l2(&resg[slot].val, 0.0); }
             }
         }
         // (b) issue the degree loads of the round
-        int ds[U], de[U]; bool want_deg[U]; u32 n_occ = 0;
+        int ds[U], de[U]; bool want_deg[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            want_deg[u] = false; ds[u] = 0; de[u] = 0;
-            if (k[u] != kEmpty) {
-                ++n_occ;
-                // deg >= 1 everywhere => a node with r < rmax can neither push nor be dangling
-                want_deg[u] = do_push && (r[u] >= p.rmax || !p.no_dangling);
-                if (want_deg[u]) { ds[u] = p.indptr[k[u]]; de[u] = p.indptr[k[u] + 1]; }   // graph.h:43-45
-            }
+            // deg >= 1 everywhere => a node with r < rmax can neither push nor be dangling
+            want_deg[u] = occ[u] && do_push && (r[u] >= p.rmax || !p.no_dangling);
+            ds[u] = 0; de[u] = 0;
+            if (want_deg[u]) { ds[u] = p.indptr[k[u]]; de[u] = p.indptr[k[u] + 1]; }       // graph.h:43-45
         }
         // (c) reserve log: one (node, coef*r) record per frontier node          graph.h:90 / :109
-        u32 li = wave_alloc(&ctl->log_count, n_occ, lane);
-        if (n_occ) {
-            if ((u64)li + n_occ <= p.log_cap) {
+        u32 li[U];
+        wave_alloc_flags<U>(&ctl->log_count, occ, li, lane);
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (k[u] != kEmpty) { log_key[li] = k[u]; log_val[li] = c * r[u]; ++li; }
-            } else {
-                ctl->fail = 1;
+        for (int u = 0; u < U; ++u) {
+            if (occ[u]) {
+                ++st_front;
+                if (li[u] < p.log_cap) { log_key[li[u]] = k[u]; log_val[li[u]] = c * r[u]; }
+                else ctl->fail = 1;
             }
-            st_front += n_occ;
         }
+        if (!do_push) continue;
         // (d) push decisions
-        u32 n_chunks = 0, e_sum = 0;
+        bool is_short[U]; u32 n_long = 0, e_sum = 0, e_short = 0;
         double share[U]; int len[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            share[u] = 0.0; len[u] = 0;
+            share[u] = 0.0; len[u] = 0; is_short[u] = false;
             if (want_deg[u]) {
                 const u32 deg = (u32)(de[u] - ds[u]);
                 if (deg == 0) {                                                      // graph.h:91-93
@@ -281,45 +346,67 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkey
                     const double sh = r[u] / (double)deg;                            // graph.h:95
                     if (sh != 0.0) {
                         share[u] = sh; len[u] = (int)deg;
-                        n_chunks += (deg + kSplitLen - 1) / kSplitLen;
                         e_sum += deg;
+                        if (deg <= (u32)kLongLen) { is_short[u] = true; e_short += deg; }
+                        else n_long += (deg + kSplitLen - 1) / kSplitLen;
                     }
                 }
             }
         }
-        // (e) wave-level compaction of the push list (prefix sums over the 64 lanes)
-        u32 pi = wave_alloc(&ctl->n_push, n_chunks, lane);
-        if (n_chunks) {
+        // (e) wave-level compaction of the push lists: short ranges fill the buffer from the
+        //     front, long-range chunks from the back
+        if (__ballot(e_sum != 0) == 0) continue;                  // wave-uniform: nobody pushes
+        u32 pi[U];
+        wave_alloc_flags<U>(&ctl->n_push, is_short, pi, lane);
+        u32 qi = 0;
+        if (__ballot(n_long != 0) != 0) qi = wave_alloc(&ctl->n_long, n_long, lane);   // hubs only
+        if (e_sum) {
             __hip_atomic_fetch_add(&ctl->e_next, e_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((u64)pi + n_chunks <= p.push_cap) {
+            if (e_short) __hip_atomic_fetch_add(&ctl->e_short, e_short, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {
+                if (len[u] == 0) continue;
+                if (is_short[u]) {
+                    // the two lists meet in the middle at worst: total entries <= push_cap by the host bound
+                    if ((u64)pi[u] + ctl->n_long < p.push_cap) {
+                        PushEntry pe; pe.start = ds[u]; pe.len = len[u]; pe.share = share[u];
+                        push[pi[u]] = pe;
+                    } else ctl->fail = 1;
+                } else {
                     for (int off = 0; off < len[u]; off += kSplitLen) {
-                        PushEntry pe;
-                        pe.start = ds[u] + off;
-                        pe.len = min(kSplitLen, len[u] - off);
-                        pe.share = share[u];
-                        push[pi++] = pe;
+                        if ((u64)qi + ctl->n_push < p.push_cap) {
+                            PushEntry pe;
+                            pe.start = ds[u] + off;
+                            pe.len = min(kSplitLen, len[u] - off);
+                            pe.share = share[u];
+                            push[p.push_cap - 1 - qi] = pe;
+                        } else ctl->fail = 1;
+                        ++qi;
                     }
                 }
-            } else {
-                ctl->fail = 1;
             }
         }
     }
 }
 
 // ---------------------------------------------------------------- EXPAND
-// G lanes (a power of two, 4..64 ~ the mean range length) cooperate on one push-list entry;
-// groups stride over the list so that every wave has work even when the list is short.
-// Lanes read consecutive column ids of the CSR range (coalesced) and add the share into the
-// next residue table; two column ids per lane are in flight before the first table update.
+// Adds `share` into the next residue table for every column id of every push-list entry
+// (graph.h:96-99).  Long entries (chunks of hub ranges) take a whole wave each; short entries
+// take G lanes (a power of two, 4..64 ~ their mean length).  Groups stride over the list so
+// every wave has work even when the list is short, and each group keeps B entries in flight:
+// the B entry loads are issued together, then the 2*B column loads, then the table updates
+// -- two exposed memory latencies per B entries instead of two per entry.
 // With parts > 1 only targets of hash partition `part` are kept (the others belong to a
 // later pass over the same list).
-template <int BLOCK, bool IN_LDS>
-__device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
-                                             ResRec* resg, u32 cap, const PushEntry* push,
-                                             u32 n_push, int log2g, u32 part, u32 parts)
+template <bool IN_LDS>
+__device__ __forceinline__ bool res_add_any(int* lkeys, double* lvals, ResRec* resg, u32 cap, int v, double share) {
+    return IN_LDS ? res_add_lds(lkeys, lvals, cap, v, share) : res_add_hbm(resg, cap, v, share);
+}
+
+template <int BLOCK, bool IN_LDS, int B>
+__device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double* lvals, ResRec* resg, u32 cap,
+                                            const PushEntry* list, long long stride_sign, u32 n_entries,
+                                            int log2g, u32 part, u32 parts)
 {
     const int tid = threadIdx.x;
     const int G = 1 << log2g;
@@ -327,40 +414,80 @@ __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lk
     const u32 gid = (u32)tid >> log2g;
     const u32 n_groups = (u32)BLOCK >> log2g;
     bool ok = true;
-    for (u32 e = gid; e < n_push; e += n_groups) {
-        const PushEntry pe = push[e];
-        const int* nbr = p.indices + pe.start;
-        const int len = pe.len;
-        const double share = pe.share;
-        int j = gl;
-        for (; j + G < len; j += 2 * G) {
-            const int v0 = nbr[j];                                          // graph.h:97
-            const int v1 = nbr[j + G];
-            const bool m0 = parts == 1 || slot_of(hash_b((u32)v0), parts) == part;
-            const bool m1 = parts == 1 || slot_of(hash_b((u32)v1), parts) == part;
-            if (IN_LDS) { if (m0) ok &= res_add_lds(lkeys, lvals, cap, v0, share);  // graph.h:98
-                          if (m1) ok &= res_add_lds(lkeys, lvals, cap, v1, share); }
-            else        { if (m0) ok &= res_add_hbm(resg, cap, v0, share);
-                          if (m1) ok &= res_add_hbm(resg, cap, v1, share); }
+    for (u32 e0 = gid; e0 < n_entries; e0 += n_groups * B) {
+        PushEntry pe[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const u32 e = e0 + (u32)b * n_groups;
+            pe[b].start = 0; pe[b].len = 0; pe[b].share = 0.0;
+            if (e < n_entries) pe[b] = list[stride_sign * (long long)e];
         }
-        if (j < len) {
-            const int v0 = nbr[j];
-            if (parts == 1 || slot_of(hash_b((u32)v0), parts) == part) {
-                if (IN_LDS) ok &= res_add_lds(lkeys, lvals, cap, v0, share);
-                else        ok &= res_add_hbm(resg, cap, v0, share);
+        int v0[B], v1[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            v0[b] = gl < pe[b].len ? p.indices[pe[b].start + gl] : -1;                  // graph.h:97
+            v1[b] = gl + G < pe[b].len ? p.indices[pe[b].start + gl + G] : -1;
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            if (v0[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v0[b]), parts) == part))
+                ok &= res_add_any<IN_LDS>(lkeys, lvals, resg, cap, v0[b], pe[b].share);   // graph.h:98
+            if (v1[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v1[b]), parts) == part))
+                ok &= res_add_any<IN_LDS>(lkeys, lvals, resg, cap, v1[b], pe[b].share);
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {                       // tails of entries longer than 2*G
+            for (int j = gl + 2 * G; j < pe[b].len; j += G) {
+                const int v = p.indices[pe[b].start + j];
+                if (parts == 1 || slot_of(hash_b((u32)v), parts) == part)
+                    ok &= res_add_any<IN_LDS>(lkeys, lvals, resg, cap, v, pe[b].share);
             }
         }
     }
+    return ok;
+}
+
+template <int BLOCK, bool IN_LDS>
+__device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
+                                             ResRec* resg, u32 cap, const PushEntry* push,
+                                             u32 n_short, u32 n_long, int log2g, u32 part, u32 parts)
+{
+    bool ok = true;
+    if (n_long)  ok &= expand_list<BLOCK, IN_LDS, 2>(p, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts);
+    if (n_short) ok &= expand_list<BLOCK, IN_LDS, 4>(p, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts);
     if (!ok) { if (IN_LDS) ctl->ovf = 1; else ctl->fail = 1; }
 }
 
 // ---------------------------------------------------------------- TOP-K
 // Candidates are ordered by the 96-bit composite (value bits, ~column): larger composite =
 // larger value, ties broken towards the SMALLER column id.  Composites are unique per row.
-typedef unsigned __int128 u128;
-__device__ __forceinline__ u128 composite(const Cand& c) {
-    return ((u128)c.bits << 32) | (u128)(u32)(~(u32)c.key);
+// The radix select walks the composite in 12-bit digits (8 of them); `depth` digits fixed so
+// far are summarised as a (hi, lo) prefix so that all arithmetic stays 64/32-bit.
+__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b) {        // a ranks before b
+    return a.bits > b.bits || (a.bits == b.bits && a.key < b.key);
 }
+struct Pre { u64 hi; u32 lo; };
+__device__ __forceinline__ Pre cand_prefix(const Cand& c, int depth) {            // top 12*depth bits
+    Pre q;
+    if (depth <= 5) { q.hi = depth == 0 ? 0ull : c.bits >> (64 - 12 * depth); q.lo = 0; }
+    else            { q.hi = c.bits; q.lo = (~(u32)c.key) >> (96 - 12 * depth); }
+    return q;
+}
+__device__ __forceinline__ u32 cand_digit(const Cand& c, int depth) {             // digit number `depth`
+    const u32 nk = ~(u32)c.key;
+    if (depth <= 4) return (u32)(c.bits >> (52 - 12 * depth)) & 0xFFFu;
+    if (depth == 5) return (((u32)c.bits & 0xFu) << 8) | (nk >> 24);
+    if (depth == 6) return (nk >> 12) & 0xFFFu;
+    return nk & 0xFFFu;
+}
+__device__ __forceinline__ Pre pre_push(Pre q, int depth, u32 digit) {            // prefix after fixing digit `depth`
+    if (depth <= 4) { q.hi = (q.hi << 12) | digit; }
+    else if (depth == 5) { q.hi = (q.hi << 4) | (digit >> 8); q.lo = digit & 0xFFu; }
+    else { q.lo = (q.lo << 12) | digit; }
+    return q;
+}
+__device__ __forceinline__ bool pre_eq(Pre a, Pre b) { return a.hi == b.hi && a.lo == b.lo; }
+__device__ __forceinline__ bool pre_gt(Pre a, Pre b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
 
 // One wave finds, in a 4096-bin histogram, the bin holding the `want`-th largest entry.
 __device__ __forceinline__ void topk_pick_bin(Ctl* ctl, const u32* hist, u32 want, int lane) {
@@ -393,7 +520,7 @@ __device__ __forceinline__ void topk_pick_bin(Ctl* ctl, const u32* hist, u32 wan
 template <int BLOCK>
 __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned char* scratch, u32 scratch_bytes,
                                          const int* log_key, const double* log_val, Cand* cand,
-                                         long long row, int seed, u64& st_filled, u64& st_support)
+                                         long long row, int seed, u64& st_filled, u64& st_support GP_SUB_PARAMS)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32*  hist = (u32*)scratch;                                      // [kTopkBins]
@@ -401,7 +528,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     Cand* tie  = sel + p.K;                                          // [kBucketCap]
     unsigned char* region = (unsigned char*)(tie + kBucketCap);
     const u32 region_bytes = scratch_bytes - (u32)(region - scratch);
-    const u32 CA = region_bytes / 12;
+    const u32 CA = (region_bytes / 12) & ~3u;
     double* avals = (double*)region;
     int* akeys = (int*)(region + 8 * (size_t)CA);
     Cand* big = (Cand*)region;
@@ -409,9 +536,12 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     const u32 n_log = ctl->log_count;
     const u32 K = (u32)p.K;
 
+    GP_SUB_BEGIN();
     // ---- 1. aggregate the log -> candidates + first histogram
     u32 parts = 1;
-    if ((u64)n_log * 4 > (u64)CA * 3) parts = (u32)(((u64)n_log * 2 + CA - 1) / CA);   // ~0.5 load per partition
+    // distinct nodes are typically ~0.6 of the records; aim at <= 0.8 load and let an overflow
+    // (detected, never silent) double the partition count
+    if ((u64)n_log * 4 > (u64)CA * 3) parts = (u32)(((u64)n_log * 3 + (u64)CA * 4 - 1) / ((u64)CA * 4));
     u64 support = 0;
     for (;;) {
         for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
@@ -421,39 +551,46 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         for (u32 part = 0; part < parts; ++part) {
             for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
             __syncthreads();
+            GP_SUB(0); GP_SUB_COUNT(8, 1);
             bool ok = true;
-            for (u32 base = 0; base < n_log; base += 2 * BLOCK) {
-                const u32 i0 = base + tid, i1 = base + BLOCK + tid;
-                int k0 = kEmpty, k1 = kEmpty; double v0 = 0.0, v1 = 0.0;
-                if (i0 < n_log) { k0 = log_key[i0]; v0 = log_val[i0]; }
-                if (i1 < n_log) { k1 = log_key[i1]; v1 = log_val[i1]; }
-                if (k0 != kEmpty && (parts == 1 || slot_of(hash_b((u32)k0), parts) == part))
-                    ok &= res_add_lds(akeys, avals, CA, k0, v0);
-                if (k1 != kEmpty && (parts == 1 || slot_of(hash_b((u32)k1), parts) == part))
-                    ok &= res_add_lds(akeys, avals, CA, k1, v1);
+            for (u32 base = 0; base < n_log && ok; base += 4 * BLOCK) {
+                if (ctl->ovf) break;                 // some other thread already gave up on this pass
+                int kk[4]; double vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const u32 i = base + (u32)u * BLOCK + tid;
+                    kk[u] = kEmpty; vv[u] = 0.0;
+                    if (i < n_log) { kk[u] = log_key[i]; vv[u] = log_val[i]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (kk[u] != kEmpty && (parts == 1 || slot_of(hash_b((u32)kk[u]), parts) == part))
+                        ok &= res_add_lds(akeys, avals, CA, kk[u], vv[u]);
             }
             if (!ok) ctl->ovf = 1;
             __syncthreads();
+            GP_SUB(1);
             if (ctl->ovf) { overflow = true; break; }
             for (u32 base = 0; base < CA; base += BLOCK) {
                 const u32 slot = base + tid;
-                u32 keep = 0;
+                bool keep = false;
                 Cand c; c.bits = 0; c.key = 0; c.pad = 0;
                 if (slot < CA) {
                     const int k = akeys[slot];
                     if (k != kEmpty) {
                         ++support;                                                   // graph.h:111 res.size()
                         const double v = avals[slot];
-                        if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); c.key = k; keep = 1; }   // graph.h:121
+                        if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); c.key = k; keep = true; }   // graph.h:121
                     }
                 }
-                const u32 ci = wave_alloc(&ctl->n_cand, keep, lane);
+                const u32 ci = wave_alloc1(&ctl->n_cand, keep, lane);
                 if (keep) {
                     if (ci < p.cand_cap) cand[ci] = c; else ctl->fail = 1;
                     __hip_atomic_fetch_add(&hist[(u32)(c.bits >> 52)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             __syncthreads();
+            GP_SUB(2);
         }
         if (!overflow) break;
         parts *= 2;                                   // a partition did not fit: split finer and redo
@@ -475,7 +612,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         const Cand* cur = cand;     // current candidate array: HBM, or `big` in LDS after compaction
         u32 cur_n = m;
         bool compacted = false;
-        u128 prefix = 0;
+        Pre prefix; prefix.hi = 0; prefix.lo = 0;
         u32 want = K;               // how many must still come from the current bucket
         int depth = 0;              // digits fixed so far
         bool take_all = false;
@@ -483,18 +620,19 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             if (depth > 0) {
                 for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
                 __syncthreads();
-                const int shift = 96 - 12 * (depth + 1);
                 for (u32 i = tid; i < cur_n; i += BLOCK) {
-                    const u128 comp = composite(cur[i]);
-                    if ((comp >> (shift + 12)) == prefix)
-                        __hip_atomic_fetch_add(&hist[(u32)(comp >> shift) & (kTopkBins - 1)], 1u,
+                    const Cand c = cur[i];
+                    if (pre_eq(cand_prefix(c, depth), prefix))
+                        __hip_atomic_fetch_add(&hist[cand_digit(c, depth)], 1u,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 __syncthreads();
             }
+            GP_SUB(3); GP_SUB_COUNT(compacted ? 10 : 9, 1);
             if (wave == 0) topk_pick_bin(ctl, hist, want, lane);
             __syncthreads();
-            prefix = (prefix << 12) | (u128)ctl->tk_bin;
+            GP_SUB(4);
+            prefix = pre_push(prefix, depth, ctl->tk_bin);
             want -= ctl->tk_above;
             const u32 cnt = ctl->tk_count;
             ++depth;
@@ -503,42 +641,41 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             if (cnt <= (u32)kBucketCap || depth == 8) break;
             if (!compacted && cnt <= big_cap) {
                 // move everything strictly above the prefix to `sel`, the bucket itself to LDS
-                const int sh = 96 - 12 * depth;
                 for (u32 base = 0; base < cur_n; base += BLOCK) {
                     const u32 i = base + tid;
-                    u32 is_sel = 0, is_b = 0;
+                    bool is_sel = false, is_b = false;
                     Cand c; c.bits = 0; c.key = 0; c.pad = 0;
                     if (i < cur_n) {
                         c = cur[i];
-                        const u128 pre = composite(c) >> sh;
-                        is_sel = pre > prefix; is_b = pre == prefix;
+                        const Pre pre = cand_prefix(c, depth);
+                        is_sel = pre_gt(pre, prefix); is_b = pre_eq(pre, prefix);
                     }
-                    const u32 si = wave_alloc(&ctl->n_sel, is_sel, lane);
+                    const u32 si = wave_alloc1(&ctl->n_sel, is_sel, lane);
                     if (is_sel) sel[si] = c;
-                    const u32 bi = wave_alloc(&ctl->n_bucket, is_b, lane);
+                    const u32 bi = wave_alloc1(&ctl->n_bucket, is_b, lane);
                     if (is_b) big[bi] = c;
                 }
                 __syncthreads();
                 cur = big; cur_n = cnt; compacted = true;
                 if (tid == 0) ctl->n_bucket = 0;
                 __syncthreads();
+                GP_SUB(5);
             }
         }
         // collect: strictly above the prefix -> selected; equal to the prefix -> tie bucket
-        const int shift = 96 - 12 * depth;
         for (u32 base = 0; base < cur_n; base += BLOCK) {
             const u32 i = base + tid;
-            u32 is_sel = 0, is_b = 0;
+            bool is_sel = false, is_b = false;
             Cand c; c.bits = 0; c.key = 0; c.pad = 0;
             if (i < cur_n) {
                 c = cur[i];
-                const u128 pre = composite(c) >> shift;
-                if (pre > prefix || (take_all && pre == prefix)) is_sel = 1;
-                else if (pre == prefix) is_b = 1;
+                const Pre pre = cand_prefix(c, depth);
+                if (pre_gt(pre, prefix) || (take_all && pre_eq(pre, prefix))) is_sel = true;
+                else if (pre_eq(pre, prefix)) is_b = true;
             }
-            const u32 si = wave_alloc(&ctl->n_sel, is_sel, lane);
+            const u32 si = wave_alloc1(&ctl->n_sel, is_sel, lane);
             if (is_sel) sel[si] = c;
-            const u32 bi = wave_alloc(&ctl->n_bucket, is_b, lane);
+            const u32 bi = wave_alloc1(&ctl->n_bucket, is_b, lane);
             if (is_b && bi < (u32)kBucketCap) tie[bi] = c;
         }
         __syncthreads();
@@ -546,21 +683,21 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             const u32 nb = min(ctl->n_bucket, (u32)kBucketCap);
             const u32 n_sel0 = ctl->n_sel;                     // == K - want
             for (u32 i = tid; i < nb; i += BLOCK) {
-                const u128 mine = composite(tie[i]);
+                const Cand mine = tie[i];
                 u32 rank = 0;
-                for (u32 j = 0; j < nb; ++j) rank += composite(tie[j]) > mine ? 1u : 0u;
-                if (rank < want) sel[n_sel0 + rank] = tie[i];
+                for (u32 j = 0; j < nb; ++j) rank += cand_better(tie[j], mine) ? 1u : 0u;
+                if (rank < want) sel[n_sel0 + rank] = mine;
             }
             __syncthreads();
         }
     }
+    GP_SUB(6);
     // order the selected `need` entries (value desc, column asc) and write the row
     const long long out0 = row * (long long)p.K;
     for (u32 i = tid; i < need; i += BLOCK) {
         const Cand c = sel[i];
-        const u128 mine = composite(c);
         u32 rank = 0;
-        for (u32 j = 0; j < need; ++j) rank += composite(sel[j]) > mine ? 1u : 0u;
+        for (u32 j = 0; j < need; ++j) rank += cand_better(sel[j], c) ? 1u : 0u;
         p.out_row[out0 + rank] = seed;                                           // graph.h:122
         p.out_col[out0 + rank] = c.key;                                          // graph.h:123
         p.out_val[out0 + rank] = __longlong_as_double((long long)c.bits);        // graph.h:124
@@ -569,6 +706,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         if (p.out_filled) p.out_filled[row] = (int)need;
         st_filled += need;
     }
+    GP_SUB(7);
 }
 
 // ---------------------------------------------------------------- the kernel
@@ -596,6 +734,10 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
     u64 tk_scan_hbm = 0, tk_expand_hbm = 0; (void)tk_scan_hbm; (void)tk_expand_hbm;
     (void)tk_scan; (void)tk_expand; (void)tk_topk; (void)tk_total; (void)t0; (void)t1; (void)t2; (void)tk_begin;
     GP_STAMP(tk_begin);
+#ifdef GP_DIAG
+    u64 gp_sub_t = 0; u64 gp_sub_acc[16];
+    for (int i = 0; i < 16; ++i) gp_sub_acc[i] = 0;
+#endif
     const int L = p.n_coef - 1;
 
     for (;;) {
@@ -616,7 +758,7 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
         }
 
         // state of the level about to be produced: its push list (built by the previous SCAN)
-        u32 n_push_cur = 0, e_cur = 0;
+        u32 n_push_cur = 0, n_long_cur = 0, e_cur = 0, e_short_cur = 0;
         double dang_cur = 0.0;
         bool has_dang_cur = false;
         int cur = 0;
@@ -635,15 +777,15 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
             u32 parts = 1, cap = 0;
             if (in_lds) {
                 if (need * 4 <= (u64)C * 3) {
-                    cap = (u32)min((u64)C, max((u64)kMinCap, 4 * need));
+                    cap = (u32)min((u64)C, max((u64)kMinCap, 3 * need)) & ~3u;
                 } else {
-                    parts = (u32)((need * 20 + (u64)C * 11 - 1) / ((u64)C * 11));      // ~0.55 load per partition
-                    cap = C;
+                    parts = (u32)((need * 20 + (u64)C * 13 - 1) / ((u64)C * 13));      // ~0.65 load per partition
+                    cap = C & ~3u;
                     if (parts > kMaxParts) in_lds = false;
                 }
             }
             int log2g = 2;                               // lanes per entry ~ mean range length
-            if (n_push_cur) { const u32 avg = e_cur / n_push_cur; while (log2g < 6 && (1u << log2g) < avg) ++log2g; }
+            if (n_push_cur) { const u32 avg = e_short_cur / n_push_cur; while (log2g < 6 && (1u << log2g) < avg) ++log2g; }
             PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
             PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
             const u64 snap_push = st_push, snap_edges = st_edges, snap_front = st_front;
@@ -657,7 +799,8 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
                 }
                 __syncthreads();
                 if (tid == 0) {
-                    ctl->n_push = 0; ctl->e_next = 0; ctl->dangling = 0.0; ctl->n_dangling = 0;
+                    ctl->n_push = 0; ctl->n_long = 0; ctl->e_next = 0; ctl->e_short = 0;
+                    ctl->dangling = 0.0; ctl->n_dangling = 0;
                     ctl->ovf = 0; ctl->log_count = snap_log;
                 }
                 __syncthreads();
@@ -667,13 +810,12 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
                         GP_STAMP(t0);
                         if (lvl == 0) {                                      // frontier { seed : 1.0 }   graph.h:81
                             if (tid == 0) {
-                                const u32 s0 = slot_of(hash_a((u32)seed), cap);
-                                if (in_lds) { lkeys[s0] = seed; lvals[s0] = 1.0; }
-                                else { st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
+                                if (in_lds) { const u32 s0 = 4 * slot_of(hash_a((u32)seed), cap >> 2); lkeys[s0] = seed; lvals[s0] = 1.0; }
+                                else { const u32 s0 = slot_of(hash_a((u32)seed), cap); st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
                             }
                         } else {
-                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, log2g, part, parts);
-                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, log2g, part, parts);
+                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, parts);
+                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, parts);
                             if (tid == 0 && has_dang_cur &&
                                 (parts == 1 || slot_of(hash_b((u32)seed), parts) == part)) {        // graph.h:92
                                 const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed, dang_cur)
@@ -700,7 +842,7 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
             }
             if (tid == 0) { if (in_lds) ++st_lds; else ++st_glb; }
             if (ctl->fail || !do_push) break;
-            n_push_cur = ctl->n_push; e_cur = ctl->e_next;
+            n_push_cur = ctl->n_push; n_long_cur = ctl->n_long; e_cur = ctl->e_next; e_short_cur = ctl->e_short;
             dang_cur = ctl->dangling; has_dang_cur = ctl->n_dangling != 0;
             cur ^= 1;
             __syncthreads();                    // everyone has read the counters before they are reset
@@ -715,7 +857,7 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
             continue;
         }
         GP_STAMP(t0);
-        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, st_filled, st_support);
+        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, st_filled, st_support GP_SUB_ARGS);
         __syncthreads();
         if (ctl->fail && tid == 0) ++st_failed;
         GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);
@@ -754,6 +896,8 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
         __hip_atomic_fetch_add(&p.counters[kTicksTotal], tk_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kTicksScanHbm], tk_scan_hbm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kTicksExpandHbm], tk_expand_hbm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 16; ++i)
+            __hip_atomic_fetch_add(&p.counters[kDiag0 + i], gp_sub_acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
 }

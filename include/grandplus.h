@@ -63,6 +63,7 @@ typedef struct gp_stats {
      * spent per phase, summed over workgroups.  Always 0 in the product library. */
     int64_t diag_ticks_scan, diag_ticks_expand, diag_ticks_topk, diag_ticks_total;
     int64_t diag_ticks_scan_hbm, diag_ticks_expand_hbm;   /* the part of scan/expand spent on HBM-table levels */
+    int64_t diag_sub[16];    /* free-form sub-phase ticks / counts of the diagnostic build          */
 } gp_stats;
 
 /* ABI / build information. */

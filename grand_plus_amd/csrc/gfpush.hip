@@ -277,7 +277,7 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         if (value != 256 && value != 512 && value != 1024) return fail(GP_ERR_INVALID_ARG, "block_threads must be 256, 512 or 1024");
         g->block_threads = (int)value;
     } else if (k == "lds_bytes") {
-        if (value < 64 * 1024 || value > 160 * 1024) return fail(GP_ERR_INVALID_ARG, "lds_bytes must be in [65536, 163840]");
+        if (value < 40 * 1024 || value > 160 * 1024) return fail(GP_ERR_INVALID_ARG, "lds_bytes must be in [40960, 163840]");
         g->lds_bytes = (int)(value & ~15ll);
     } else if (k == "max_workgroups") {
         if (value < 0 || value > 65535) return fail(GP_ERR_INVALID_ARG, "max_workgroups must be in [0, 65535]");
@@ -309,7 +309,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
 
     // LDS table geometry: 12 B per slot after the control block; top-K scratch must fit in it
     const int lds_bytes = g->lds_bytes;
-    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~3u;     // bucketed probing: multiple of 4
+    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~1u;     // even: keeps the key array 8-byte aligned
     if ((size_t)lds_slots * 12 < kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap)
         return fail(GP_ERR_INVALID_ARG, "lds_bytes too small for K = %d", K);
 

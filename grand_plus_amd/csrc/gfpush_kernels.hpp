@@ -55,7 +55,7 @@ constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= 
 constexpr int    kCtlBytes   = 256;     // control block at the start of dynamic LDS
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 8;       // most hash partitions a level is expanded in before using the HBM table
-constexpr u32    kMaxProbe   = 16;      // an LDS insert that walks this many 4-key buckets reports overflow
+constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many slots reports overflow
                                         // (recoverable: the level / aggregation is redone in more partitions)
 
 struct PushEntry { int start; int len; double share; };  // 16 B
@@ -128,12 +128,13 @@ struct KParams {
 };
 
 // ---------------------------------------------------------------- small helpers
-__device__ __forceinline__ u32 hash_a(u32 k) {            // residue tables
-    k *= 0x9E3779B1u; k ^= k >> 15; k *= 0x85EBCA77u; k ^= k >> 13;
+// Multiplicative (Fibonacci-style) hashes; slot_of() consumes the HIGH bits.
+__device__ __forceinline__ u32 hash_a(u32 k) {            // residue / aggregation tables
+    k *= 0x9E3779B1u; k ^= k >> 15; k *= 0x85EBCA77u;
     return k;
 }
 __device__ __forceinline__ u32 hash_b(u32 k) {            // partition choice (independent of hash_a)
-    k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; k *= 0x846CA68Bu; k ^= k >> 16;
+    k *= 0x7FEB352Du; k ^= k >> 16; k *= 0x846CA68Bu;
     return k;
 }
 __device__ __forceinline__ u32 slot_of(u32 h, u32 cap) { return (u32)(((u64)h * cap) >> 32); }
@@ -214,41 +215,25 @@ __device__ __forceinline__ void wave_alloc_flags(u32* lds_counter, const bool (&
 }
 
 // ---------------------------------------------------------------- residue tables
-// LDS table insert-or-add.  The table is probed in BUCKETS of 4 keys (two 64-bit LDS loads):
-// a wave pays the maximum probe count over its 64 lanes, and with one key per probe that
-// maximum is tens of iterations at load 0.6-0.7; with 4 keys per probe it is 1-3.
-// `cap` must be a multiple of 4 and `keys` 16-byte aligned.  Keys never revert to EMPTY
-// while inserts are running, which is what makes "claim the first EMPTY slot, re-read the
-// bucket if the claim lost" produce at most one slot per key.
+// LDS table insert-or-add.  One LDS compare-and-swap per probe does everything: the value it
+// returns says whether the slot was EMPTY (now claimed for k), already held k, or belongs to
+// another key (walk on, triangular steps).  No pre-read, no nested branches: the loop body is
+// a handful of instructions, which matters because this path is instruction-issue bound.
+// Keys never revert to EMPTY while inserts are running, so a key ends up in exactly one slot.
 __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {
-    const u32 nb = cap >> 2;
-    u32 b = slot_of(hash_a((u32)k), nb);
-    const u32 max_probe = nb < kMaxProbe ? nb : kMaxProbe;
-    const u64* keys64 = (const u64*)keys;
-    for (u32 probe = 0; probe < max_probe;) {
-        const u64 lo = __hip_atomic_load(&keys64[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const u64 hi = __hip_atomic_load(&keys64[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int k0 = (int)(u32)lo, k1 = (int)(u32)(lo >> 32), k2 = (int)(u32)hi, k3 = (int)(u32)(hi >> 32);
-        int idx = k0 == k ? 0 : k1 == k ? 1 : k2 == k ? 2 : k3 == k ? 3 : -1;
-        if (idx < 0) {
-            const int e = k0 == kEmpty ? 0 : k1 == kEmpty ? 1 : k2 == kEmpty ? 2 : k3 == kEmpty ? 3 : -1;
-            if (e >= 0) {
-                int expect = kEmpty;
-                if (__hip_atomic_compare_exchange_strong(&keys[4 * b + e], &expect, k, __ATOMIC_RELAXED,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || expect == k)
-                    idx = e;
-                else
-                    continue;               // another key claimed that slot first: look at the bucket again
-            }
-        }
-        if (idx >= 0) {
-            __hip_atomic_fetch_add(&vals[4 * b + idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return true;
-        }
-        b = (b + 1 == nb) ? 0 : b + 1;
-        ++probe;
+    u32 slot = slot_of(hash_a((u32)k), cap);
+    bool done = false;
+#pragma unroll 1
+    for (u32 step = 1; step <= kMaxProbe; ++step) {
+        int seen = kEmpty;
+        __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen == kEmpty || seen == k) { done = true; break; }
+        slot += step;
+        if (slot >= cap) slot -= cap;
     }
-    return false;
+    if (done) __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return done;
 }
 
 __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double v) {
@@ -528,7 +513,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     Cand* tie  = sel + p.K;                                          // [kBucketCap]
     unsigned char* region = (unsigned char*)(tie + kBucketCap);
     const u32 region_bytes = scratch_bytes - (u32)(region - scratch);
-    const u32 CA = (region_bytes / 12) & ~3u;
+    const u32 CA = region_bytes / 12;
     double* avals = (double*)region;
     int* akeys = (int*)(region + 8 * (size_t)CA);
     Cand* big = (Cand*)region;
@@ -541,7 +526,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     u32 parts = 1;
     // distinct nodes are typically ~0.6 of the records; aim at <= 0.8 load and let an overflow
     // (detected, never silent) double the partition count
-    if ((u64)n_log * 4 > (u64)CA * 3) parts = (u32)(((u64)n_log * 3 + (u64)CA * 4 - 1) / ((u64)CA * 4));
+    if ((u64)n_log * 10 > (u64)CA * 6) parts = (u32)(((u64)n_log * 6 + (u64)CA * 5 - 1) / ((u64)CA * 5));
     u64 support = 0;
     for (;;) {
         for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
@@ -710,8 +695,11 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
 }
 
 // ---------------------------------------------------------------- the kernel
+// Register budget: 1024 threads = 4 waves/SIMD = 128 VGPRs.  The 512- and 256-thread forms are
+// built for the SAME 4 waves/SIMD so that 2 (resp. 4) workgroups can share a CU and overlap
+// one row's barriers and memory stalls with another row's work.
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
+__global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctl* ctl   = (Ctl*)smem;
@@ -777,10 +765,10 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
             u32 parts = 1, cap = 0;
             if (in_lds) {
                 if (need * 4 <= (u64)C * 3) {
-                    cap = (u32)min((u64)C, max((u64)kMinCap, 3 * need)) & ~3u;
+                    cap = (u32)min((u64)C, max((u64)kMinCap, 4 * need));
                 } else {
-                    parts = (u32)((need * 20 + (u64)C * 13 - 1) / ((u64)C * 13));      // ~0.65 load per partition
-                    cap = C & ~3u;
+                    parts = (u32)((need * 20 + (u64)C * 11 - 1) / ((u64)C * 11));      // ~0.55 load per partition (edges; distinct is less)
+                    cap = C;
                     if (parts > kMaxParts) in_lds = false;
                 }
             }
@@ -810,7 +798,7 @@ __global__ void __launch_bounds__(BLOCK) gfpush_kernel(const KParams p)
                         GP_STAMP(t0);
                         if (lvl == 0) {                                      // frontier { seed : 1.0 }   graph.h:81
                             if (tid == 0) {
-                                if (in_lds) { const u32 s0 = 4 * slot_of(hash_a((u32)seed), cap >> 2); lkeys[s0] = seed; lvals[s0] = 1.0; }
+                                if (in_lds) { const u32 s0 = slot_of(hash_a((u32)seed), cap); lkeys[s0] = seed; lvals[s0] = 1.0; }
                                 else { const u32 s0 = slot_of(hash_a((u32)seed), cap); st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
                             }
                         } else {

@@ -523,17 +523,24 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
 
     GP_SUB_BEGIN();
     // ---- 1. aggregate the log -> candidates + first histogram
-    u32 parts = 1;
-    // distinct nodes are typically ~0.6 of the records; aim at <= 0.8 load and let an overflow
-    // (detected, never silent) double the partition count
-    if ((u64)n_log * 10 > (u64)CA * 6) parts = (u32)(((u64)n_log * 6 + (u64)CA * 5 - 1) / ((u64)CA * 5));
+    // Key partitions are (p, P) = "keys whose hash falls in the p-th of P equal ranges".  A
+    // partition that does not fit the table is split into (2p, 2P) and (2p+1, 2P) -- exactly
+    // its two halves under the multiply-high mapping -- and nothing has to be undone, because
+    // overflow is detected before the partition's table is turned into candidates.
+    u32 P0 = 1;
+    // distinct nodes are typically ~0.6 of the records: aim at ~0.7 load
+    if ((u64)n_log * 10 > (u64)CA * 6) P0 = (u32)(((u64)n_log * 6 + (u64)CA * 5 - 1) / ((u64)CA * 5));
     u64 support = 0;
-    for (;;) {
-        for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
-        if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
-        support = 0;
-        bool overflow = false;
-        for (u32 part = 0; part < parts; ++part) {
+    for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+    if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
+    // work stack: at most one pending sibling per refinement depth
+    u32 stk_p[20], stk_P[20]; int sp = 0;
+    for (u32 q = P0; q-- > 0;) {
+        // process partition (q, P0) and whatever it gets split into, depth first
+        stk_p[0] = q; stk_P[0] = P0; sp = 1;
+        while (sp > 0) {
+            --sp;
+            const u32 part = stk_p[sp], parts = stk_P[sp];
             for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
             __syncthreads();
             GP_SUB(0); GP_SUB_COUNT(8, 1);
@@ -555,7 +562,17 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             if (!ok) ctl->ovf = 1;
             __syncthreads();
             GP_SUB(1);
-            if (ctl->ovf) { overflow = true; break; }
+            if (ctl->ovf) {
+                __syncthreads();
+                if (tid == 0) ctl->ovf = 0;
+                if (sp + 2 <= 20 && parts < 0x40000000u) {
+                    stk_p[sp] = 2 * part + 1; stk_P[sp] = 2 * parts; ++sp;
+                    stk_p[sp] = 2 * part;     stk_P[sp] = 2 * parts; ++sp;
+                } else if (tid == 0) {
+                    ctl->fail = 1;                   // cannot happen for a sane hash; reported, not silent
+                }
+                continue;
+            }
             for (u32 base = 0; base < CA; base += BLOCK) {
                 const u32 slot = base + tid;
                 bool keep = false;
@@ -577,9 +594,6 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             __syncthreads();
             GP_SUB(2);
         }
-        if (!overflow) break;
-        parts *= 2;                                   // a partition did not fit: split finer and redo
-        __syncthreads();
     }
     st_support += support;
     const u32 m = ctl->n_cand;
@@ -776,36 +790,39 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             if (n_push_cur) { const u32 avg = e_short_cur / n_push_cur; while (log2g < 6 && (1u << log2g) < avg) ++log2g; }
             PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
             PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
-            const u64 snap_push = st_push, snap_edges = st_edges, snap_front = st_front;
-            const u32 snap_log = ctl->log_count;
-
-            for (;;) {      // normally one trip; repeats only if an LDS partition overflowed
-                if (!in_lds) {
-                    parts = 1;
-                    if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; }
-                    cap = (u32)min(p.resg_cap, max((u64)kMinCap, 2 * need));
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    ctl->n_push = 0; ctl->n_long = 0; ctl->e_next = 0; ctl->e_short = 0;
-                    ctl->dangling = 0.0; ctl->n_dangling = 0;
-                    ctl->ovf = 0; ctl->log_count = snap_log;
-                }
-                __syncthreads();
-                bool overflow = false;
-                if (!ctl->fail) {
-                    for (u32 part = 0; part < parts; ++part) {
+            if (!in_lds) {
+                parts = 1;
+                if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; }
+                cap = (u32)min(p.resg_cap, max((u64)kMinCap, 2 * need));
+            }
+            __syncthreads();
+            if (tid == 0) {
+                ctl->n_push = 0; ctl->n_long = 0; ctl->e_next = 0; ctl->e_short = 0;
+                ctl->dangling = 0.0; ctl->n_dangling = 0; ctl->ovf = 0;
+            }
+            __syncthreads();
+            // Hash partitions (q, P) of the level's targets, refined in place on overflow exactly
+            // like the aggregation partitions of topk_row (nothing to undo: a partition is
+            // scanned only after its expansion succeeded).
+            if (!ctl->fail) {
+                u32 stk_p[16], stk_P[16];
+                for (u32 q = parts; q-- > 0 && !ctl->fail;) {
+                    int sp = 1; stk_p[0] = q; stk_P[0] = parts;
+                    while (sp > 0) {
+                        --sp;
+                        const u32 part = stk_p[sp], np = stk_P[sp];
                         GP_STAMP(t0);
                         if (lvl == 0) {                                      // frontier { seed : 1.0 }   graph.h:81
                             if (tid == 0) {
-                                if (in_lds) { const u32 s0 = slot_of(hash_a((u32)seed), cap); lkeys[s0] = seed; lvals[s0] = 1.0; }
-                                else { const u32 s0 = slot_of(hash_a((u32)seed), cap); st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
+                                const u32 s0 = slot_of(hash_a((u32)seed), cap);
+                                if (in_lds) { lkeys[s0] = seed; lvals[s0] = 1.0; }
+                                else { st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
                             }
                         } else {
-                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, parts);
-                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, parts);
+                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
+                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
                             if (tid == 0 && has_dang_cur &&
-                                (parts == 1 || slot_of(hash_b((u32)seed), parts) == part)) {        // graph.h:92
+                                (np == 1 || slot_of(hash_b((u32)seed), np) == part)) {              // graph.h:92
                                 const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed, dang_cur)
                                                        : res_add_hbm(resg, cap, seed, dang_cur);
                                 if (!ok) { if (in_lds) ctl->ovf = 1; else ctl->fail = 1; }
@@ -813,7 +830,21 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                         }
                         __syncthreads();
                         GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1); if (!in_lds) GP_ACCUM(tk_expand_hbm, t0, t1);
-                        if (ctl->ovf || ctl->fail) { overflow = ctl->ovf != 0; break; }
+                        if (ctl->fail) break;
+                        if (ctl->ovf) {
+                            // this partition did not fit: wipe the table and split it in two
+                            for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+                            __syncthreads();
+                            if (tid == 0) ctl->ovf = 0;
+                            if (sp + 2 <= 16 && np < 0x40000000u) {
+                                stk_p[sp] = 2 * part + 1; stk_P[sp] = 2 * np; ++sp;
+                                stk_p[sp] = 2 * part;     stk_P[sp] = 2 * np; ++sp;
+                            } else if (tid == 0) {
+                                ctl->fail = 1;
+                            }
+                            __syncthreads();
+                            continue;
+                        }
                         if (in_lds) scan_level<BLOCK, true,  4>(p, ctl, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
                         else        scan_level<BLOCK, false, 4>(p, ctl, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
                         __syncthreads();
@@ -821,12 +852,6 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                         if (ctl->fail) break;
                     }
                 }
-                if (ctl->fail || !overflow) break;
-                // an LDS partition overflowed: wipe the table, forget this level's output, split finer
-                for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
-                st_push = snap_push; st_edges = snap_edges; st_front = snap_front;
-                parts *= 2;
-                if (parts > kMaxParts) in_lds = false;
             }
             if (tid == 0) { if (in_lds) ++st_lds; else ++st_glb; }
             if (ctl->fail || !do_push) break;

@@ -20,6 +20,11 @@ def shard_range(n_seeds: int, world: int, rank: int):
     return lo, hi, per
 
 
+def packed_stride(per: int, K: int) -> int:
+    """Bytes one rank contributes to the all-gather: [val f64 | row i32 | col i32 | filled i32], 16-B padded."""
+    return (16 * per * K + 4 * per + 15) // 16 * 16
+
+
 class PackedRows:
     """One contiguous byte buffer holding `per` rows of K slots, with typed views into it."""
 
@@ -27,7 +32,7 @@ class PackedRows:
         import torch
         n = per * K
         self.per, self.K = per, K
-        self.nbytes = 16 * n + 4 * per
+        self.nbytes = packed_stride(per, K)          # padded so that every rank's slice stays 16-byte aligned
         self.buf = torch.zeros(max(self.nbytes, 8), dtype=torch.uint8, device=device)
         self.val = self.buf[0:8 * n].view(torch.float64)
         self.row = self.buf[8 * n:12 * n].view(torch.int32)
@@ -39,7 +44,7 @@ def unpack_gathered(gathered, world: int, per: int, K: int, n_seeds: int):
     """Split the all-gathered byte buffer back into (row, col, val, filled) of the first n_seeds rows."""
     import torch
     n = per * K
-    stride = 16 * n + 4 * per
+    stride = packed_stride(per, K)
     rows, cols, vals, fills = [], [], [], []
     for r in range(world):
         part = gathered[r * stride:(r + 1) * stride]

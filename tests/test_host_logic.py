@@ -1,0 +1,144 @@
+"""CPU tests of the host logic: C-ABI exports, error behaviour without a GPU, caller-side
+recipes, the tie-aware comparator, the synthetic generator's committed checksums."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "grandplus.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from grand_plus_amd import _native
+    declared = _declared_symbols()
+    assert declared == sorted(_native.EXPORTS)
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libgrandplus.so does not export {name}"
+    assert _native.lib().gp_abi_version() == 1
+    assert _native.lib().gp_strerror(2) == b"invalid CSR"
+
+
+def test_stats_struct_matches_header():
+    from grand_plus_amd import _native
+    text = open(os.path.join(ROOT, "include", "grandplus.h")).read()
+    body = text[text.index("typedef struct gp_stats {"):text.index("} gp_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"(?:int64_t|int32_t|double)\s+([^;]+);", body):
+        for item in decl.split(","):
+            names.append(re.sub(r"\[.*\]", "", item).strip())
+    assert names == [n for n, _ in _native.GpStats._fields_]
+
+
+def test_pybind_module_surface_is_the_references():
+    from precompute import propagation                 # model.py:9 import path
+    public = [n for n in dir(propagation) if not n.startswith("_")]
+    assert public == ["Graph"]
+    assert [n for n in dir(propagation.Graph) if not n.startswith("_")] == ["gfpush_omp"]
+
+
+def _no_gpu():
+    from grand_plus_amd import _native
+    return _native.lib().gp_device_count() == 0
+
+
+def test_errors_before_any_gpu_work():
+    from grand_plus_amd import Graph
+    from precompute import propagation
+    ok_ptr, ok_idx = np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32)
+    for ctor in (Graph, propagation.Graph):
+        with pytest.raises(ValueError):
+            ctor(np.array([0, 2, 1], np.int32), ok_idx, 0)            # indptr decreases
+        with pytest.raises(ValueError):
+            ctor(ok_ptr, np.array([0, 9], np.int32), 0)               # column out of range
+        with pytest.raises(ValueError):
+            ctor(np.array([1, 1, 2], np.int32), ok_idx, 0)            # indptr[0] != 0
+    if _no_gpu():
+        for ctor in (Graph, propagation.Graph):
+            with pytest.raises(RuntimeError, match="no HIP device|no CPU path"):
+                ctor(ok_ptr, ok_idx, 0)                               # fails loudly: no CPU fallback
+
+
+def test_output_dtype_guard_python_mirror():
+    from grand_plus_amd import api
+    with pytest.raises(TypeError):
+        api._check_out(np.zeros(4, np.int64), np.int32, "row_idx", 4)     # KAT-7: reference silently drops
+    with pytest.raises(TypeError):
+        api._check_out(np.zeros(4, np.float32), np.float64, "value", 4)
+    with pytest.raises(TypeError):
+        api._check_out(np.zeros(8, np.int32)[::2], np.int32, "col_idx", 4)
+    with pytest.raises(ValueError):
+        api._check_out(np.zeros(3, np.int32), np.int32, "row_idx", 4)
+    api._check_out(np.zeros(4, np.int32), np.int32, "row_idx", 4)
+    assert api._as_i32_readonly(np.array([1, 2], np.int64), "node_idx").dtype == np.int32
+
+
+def test_make_coef_follows_reference_recipe():
+    from grand_plus_amd.recipes import make_coef, add_self_loops_csr
+    c = make_coef("ppr", 3, 0.2)
+    ref = [0.2]
+    for _ in range(3):
+        ref.append(ref[-1] * 0.8)
+    np.testing.assert_array_equal(c, np.asarray(ref) / np.sum(ref))
+    np.testing.assert_array_equal(make_coef("avg", 4), np.full(5, 0.2))
+    np.testing.assert_array_equal(make_coef("single", 2), np.array([0.0, 0.0, 1.0]))
+    with pytest.raises(ValueError, match="Unknown propagation mode"):
+        make_coef("heat", 2)
+    ip, ix = add_self_loops_csr(np.array([0, 1, 1, 2], np.int32), np.array([1, 2], np.int32))
+    assert ip.tolist() == [0, 2, 3, 4] and ix.tolist() == [0, 1, 1, 2]   # node 2 already had its loop
+
+
+def test_comparator_is_tie_aware_but_strict():
+    from grand_plus_amd.parity import compare_rows
+    seeds, K = np.array([5]), 3
+    exp = (np.array([5, 5, 5], np.int32), np.array([1, 2, 3], np.int32), np.array([.5, .25, .125]))
+    tie = (np.array([5, 5, 5], np.int32), np.array([1, 2, 9], np.int32), np.array([.5, .25, .125]))
+    assert compare_rows(seeds, K, tie, exp).ok                        # col 9 ties with the K-th value
+    assert compare_rows(seeds, K, tie, exp).tie_rows == 1
+    bad_val = (exp[0], exp[1], np.array([.5, .25, .126]))
+    assert not compare_rows(seeds, K, bad_val, exp).ok
+    missing = (exp[0], np.array([1, 9, 3], np.int32), np.array([.5, .2, .125]))
+    assert not compare_rows(seeds, K, missing, exp).ok                # col 2 is clearly above the K-th value
+    fewer = (np.array([5, 5, 0], np.int32), np.array([1, 2, 0], np.int32), np.array([.5, .25, 0.]))
+    assert not compare_rows(seeds, K, fewer, exp).ok                  # filled count differs
+    wrong_row = (np.array([4, 5, 5], np.int32), exp[1], exp[2])
+    assert not compare_rows(seeds, K, wrong_row, exp).ok
+
+
+@pytest.mark.parametrize("shape", ["tiny", "small", "reddit"])
+def test_synthetic_generator_is_bit_reproducible(shape):
+    from grand_plus_amd import synth
+    meta = json.load(open(os.path.join(GOLD, "golden_meta.json")))["synthetic_checksums"][shape]
+    indptr, indices = synth.shape_csr(shape)
+    assert len(indices) == meta["nnz"] and int(np.diff(indptr).max()) == meta["max_degree"]
+    assert f"{synth.checksum64(indptr):016x}" == meta["indptr"]
+    assert f"{synth.checksum64(indices):016x}" == meta["indices"]
+    n = len(indptr) - 1
+    assert f"{synth.checksum64(synth.seeds(n, min(1024, n))):016x}" == meta["seeds1024"]
+    # structure: symmetric, self-loop on every node, sorted unique columns
+    deg = np.diff(indptr)
+    assert deg.min() >= 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), deg)
+    key = rows * n + indices
+    assert (np.diff(key) > 0).all()
+    rev = np.sort(indices.astype(np.int64) * n + rows)
+    np.testing.assert_array_equal(rev, key)
+    assert (indices[indptr[:-1] + np.searchsorted(key, rows[indptr[:-1]] * n + np.arange(n)) - indptr[:-1]] == np.arange(n)).all()
+
+
+def test_synth_seeds_are_a_permutation_prefix():
+    from grand_plus_amd import synth
+    s = synth.seeds(1000, 1000)
+    assert sorted(s.tolist()) == list(range(1000))
+    np.testing.assert_array_equal(synth.seeds(1000, 10), s[:10])

@@ -57,7 +57,7 @@ struct gp_graph {
     int num_cus = 0;
     // options
     int block_threads = 1024; int lds_bytes = 160 * 1024; int max_workgroups = 0;
-    int64_t workspace_mb = 65536; int force_global = 0;
+    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0;
     // per-call state
     Workspace ws;
     u64* d_counters = nullptr; u64* h_counters = nullptr;      // pinned host mirror
@@ -287,6 +287,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         g->workspace_mb = value;
     } else if (k == "force_global") {
         g->force_global = value ? 1 : 0;
+    } else if (k == "exact_stats") {
+        g->exact_stats = value ? 1 : 0;
     } else {
         return fail(GP_ERR_INVALID_ARG, "unknown option '%s'", key);
     }
@@ -360,6 +362,8 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.lds_slots = lds_slots;
     kp.no_dangling = g->no_dangling;
     kp.force_global = g->force_global;
+    kp.prune = g->exact_stats ? 0 : 1;
+    for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
 
     HIP_TRY(hipEventRecord(g->ev0, s));
     if (n_seeds > 0) {

@@ -125,6 +125,7 @@ struct KParams {
     u32 lds_slots;
     int no_dangling;                      // 1 when every node has degree >= 1
     int force_global;
+    int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -234,6 +235,34 @@ __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, in
     }
     if (done) __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return done;
+}
+
+// Claim a slot for k without touching its value (same probe sequence as res_add_lds).
+__device__ __forceinline__ bool lds_claim(int* keys, u32 cap, int k) {
+    u32 slot = slot_of(hash_a((u32)k), cap);
+#pragma unroll 1
+    for (u32 step = 1; step <= kMaxProbe; ++step) {
+        int seen = kEmpty;
+        __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen == kEmpty || seen == k) return true;
+        slot += step;
+        if (slot >= cap) slot -= cap;
+    }
+    return false;
+}
+// Read-only lookup (no inserts may run concurrently): slot of k, or -1.
+__device__ __forceinline__ int lds_find(const int* keys, u32 cap, int k) {
+    u32 slot = slot_of(hash_a((u32)k), cap);
+#pragma unroll 1
+    for (u32 step = 1; step <= kMaxProbe; ++step) {
+        const int seen = keys[slot];
+        if (seen == k) return (int)slot;
+        if (seen == kEmpty) return -1;
+        slot += step;
+        if (slot >= cap) slot -= cap;
+    }
+    return -1;
 }
 
 __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double v) {
@@ -480,6 +509,10 @@ __device__ __forceinline__ void topk_pick_bin(Ctl* ctl, const u32* hist, u32 wan
     u32 csum = 0;
     for (int j = 0; j < 64; ++j) csum += hist[64 * lane + ((j + lane) & 63)];
     const u32 csuf = wave_suffix_scan(csum, lane);              // bins >= 64*lane
+    if ((u32)__shfl(csuf, 0) < want) {                          // fewer than `want` entries in total
+        if (lane == 0) { ctl->tk_bin = 0xFFFFFFFFu; ctl->tk_above = 0; ctl->tk_count = 0; }
+        return;
+    }
     const u64 cm = __ballot(csuf >= want);
     const int cl = __popcll(cm) - 1;                            // chunk holding the want-th largest
     const u32 above_c = __shfl(csuf, cl) - __shfl(csum, cl);    // bins above that chunk
@@ -505,7 +538,8 @@ __device__ __forceinline__ void topk_pick_bin(Ctl* ctl, const u32* hist, u32 wan
 template <int BLOCK>
 __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned char* scratch, u32 scratch_bytes,
                                          const int* log_key, const double* log_val, Cand* cand,
-                                         long long row, int seed, u64& st_filled, u64& st_support GP_SUB_PARAMS)
+                                         long long row, int seed, u32 seg_begin, u32 seg_len, int n_levels,
+                                         u64& st_filled, u64& st_support GP_SUB_PARAMS)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32*  hist = (u32*)scratch;                                      // [kTopkBins]
@@ -521,8 +555,107 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     const u32 n_log = ctl->log_count;
     const u32 K = (u32)p.K;
 
+    // turns the occupied slots of the aggregation table into candidates (+ first-digit histogram)
+    auto emit_candidates = [&](u64& n_nodes) {
+        for (u32 base = 0; base < CA; base += BLOCK) {
+            const u32 slot = base + tid;
+            bool keep = false;
+            Cand c; c.bits = 0; c.key = 0; c.pad = 0;
+            if (slot < CA) {
+                const int k = akeys[slot];
+                if (k != kEmpty) {
+                    ++n_nodes;                                                   // graph.h:111 res.size()
+                    const double v = avals[slot];
+                    if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); c.key = k; keep = true; }   // graph.h:121
+                }
+            }
+            const u32 ci = wave_alloc1(&ctl->n_cand, keep, lane);
+            if (keep) {
+                if (ci < p.cand_cap) cand[ci] = c; else ctl->fail = 1;
+                __hip_atomic_fetch_add(&hist[(u32)(c.bits >> 52)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
     GP_SUB_BEGIN();
-    // ---- 1. aggregate the log -> candidates + first histogram
+    // ---- 0. threshold-pruned aggregation (exact; applies when every coef >= 0)
+    // A node's total is >= each of its records, and the records of ONE level belong to distinct
+    // nodes, so the K-th largest record of the biggest level is a lower bound tau on the final
+    // K-th largest total.  A node all of whose (<= n_levels) records are below tau/n_levels sums
+    // to less than tau and cannot be selected.  Pass A claims table slots only for nodes owning a
+    // record >= tau/n_levels, pass B adds ALL records of claimed nodes (read-only probe).  tau is
+    // taken as the lower edge of the binade holding that K-th record (one histogram pass).
+    bool pruned_done = false;
+    u64 live_nodes = 0;
+    if (p.prune && seg_len >= 4 * K && n_levels >= 1) {
+        for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+        if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
+        __syncthreads();
+        for (u32 i = tid; i < seg_len; i += BLOCK) {
+            const double v = log_val[seg_begin + i];
+            if (v > 0.0)
+                __hip_atomic_fetch_add(&hist[(u32)((u64)__double_as_longlong(v) >> 52)], 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        if (wave == 0) topk_pick_bin(ctl, hist, K, lane);
+        __syncthreads();
+        const u32 bin = ctl->tk_bin;
+        __syncthreads();
+        if (bin != 0xFFFFFFFFu && bin != 0) {
+            const double tau = __longlong_as_double((long long)((u64)bin << 52));
+            const double thr = tau / (double)n_levels * 0.99999;
+            for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
+            __syncthreads();
+            GP_SUB(0);
+            bool ok = true;
+            for (u32 base = 0; base < n_log && ok; base += 4 * BLOCK) {          // pass A: claim
+                int kk[4]; double vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const u32 i = base + (u32)u * BLOCK + tid;
+                    kk[u] = kEmpty; vv[u] = 0.0;
+                    if (i < n_log) { vv[u] = log_val[i]; if (vv[u] >= thr) kk[u] = log_key[i]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (kk[u] != kEmpty) ok &= lds_claim(akeys, CA, kk[u]);
+            }
+            if (!ok) ctl->ovf = 1;
+            __syncthreads();
+            if (!ctl->ovf) {
+                for (u32 base = 0; base < n_log; base += 4 * BLOCK) {            // pass B: add
+                    int kk[4]; double vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 i = base + (u32)u * BLOCK + tid;
+                        kk[u] = kEmpty; vv[u] = 0.0;
+                        if (i < n_log) { kk[u] = log_key[i]; vv[u] = log_val[i]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (kk[u] == kEmpty) continue;
+                        const int slot = lds_find(akeys, CA, kk[u]);
+                        if (slot >= 0)
+                            __hip_atomic_fetch_add(&avals[slot], vv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+                __syncthreads();
+                GP_SUB(1);
+                emit_candidates(live_nodes);
+                __syncthreads();
+                GP_SUB(2); GP_SUB_COUNT(11, 1);
+                pruned_done = true;
+            } else {
+                __syncthreads();
+                if (tid == 0) ctl->ovf = 0;              // too many live nodes for one table: full path
+                __syncthreads();
+            }
+        }
+    }
+    // ---- 1. full aggregation of the log -> candidates + first histogram
+    u64 support = 0;
+    if (!pruned_done) {
     // Key partitions are (p, P) = "keys whose hash falls in the p-th of P equal ranges".  A
     // partition that does not fit the table is split into (2p, 2P) and (2p+1, 2P) -- exactly
     // its two halves under the multiply-high mapping -- and nothing has to be undone, because
@@ -530,7 +663,6 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     u32 P0 = 1;
     // distinct nodes are typically ~0.6 of the records: aim at ~0.7 load
     if ((u64)n_log * 10 > (u64)CA * 6) P0 = (u32)(((u64)n_log * 6 + (u64)CA * 5 - 1) / ((u64)CA * 5));
-    u64 support = 0;
     for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
     if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
     // work stack: at most one pending sibling per refinement depth
@@ -573,29 +705,13 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                 }
                 continue;
             }
-            for (u32 base = 0; base < CA; base += BLOCK) {
-                const u32 slot = base + tid;
-                bool keep = false;
-                Cand c; c.bits = 0; c.key = 0; c.pad = 0;
-                if (slot < CA) {
-                    const int k = akeys[slot];
-                    if (k != kEmpty) {
-                        ++support;                                                   // graph.h:111 res.size()
-                        const double v = avals[slot];
-                        if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); c.key = k; keep = true; }   // graph.h:121
-                    }
-                }
-                const u32 ci = wave_alloc1(&ctl->n_cand, keep, lane);
-                if (keep) {
-                    if (ci < p.cand_cap) cand[ci] = c; else ctl->fail = 1;
-                    __hip_atomic_fetch_add(&hist[(u32)(c.bits >> 52)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
+            emit_candidates(support);
             __syncthreads();
             GP_SUB(2);
         }
     }
-    st_support += support;
+    }
+    st_support += pruned_done ? live_nodes : support;
     const u32 m = ctl->n_cand;
     const u32 need = m < K ? m : K;                                   // graph.h:113
     if (need == 0 || ctl->fail) {
@@ -761,6 +877,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
 
         // state of the level about to be produced: its push list (built by the previous SCAN)
         u32 n_push_cur = 0, n_long_cur = 0, e_cur = 0, e_short_cur = 0;
+        u32 seg_begin = 0, seg_len = 0; int n_levels = 0;     // biggest level of the reserve log (coef > 0)
         double dang_cur = 0.0;
         bool has_dang_cur = false;
         int cur = 0;
@@ -790,6 +907,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             if (n_push_cur) { const u32 avg = e_short_cur / n_push_cur; while (log2g < 6 && (1u << log2g) < avg) ++log2g; }
             PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
             PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
+            const u32 snap_log = ctl->log_count;          // first log record of this level
             if (!in_lds) {
                 parts = 1;
                 if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; }
@@ -854,6 +972,11 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                 }
             }
             if (tid == 0) { if (in_lds) ++st_lds; else ++st_glb; }
+            {
+                const u32 lvl_len = ctl->log_count - snap_log;      // read after the level's last barrier
+                n_levels = lvl + 1;
+                if (c > 0.0 && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
+            }
             if (ctl->fail || !do_push) break;
             n_push_cur = ctl->n_push; n_long_cur = ctl->n_long; e_cur = ctl->e_next; e_short_cur = ctl->e_short;
             dang_cur = ctl->dangling; has_dang_cur = ctl->n_dangling != 0;
@@ -870,7 +993,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             continue;
         }
         GP_STAMP(t0);
-        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, st_filled, st_support GP_SUB_ARGS);
+        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, seg_begin, seg_len, n_levels, st_filled, st_support GP_SUB_ARGS);
         __syncthreads();
         if (ctl->fail && tid == 0) ++st_failed;
         GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);

@@ -48,7 +48,7 @@ typedef struct gp_stats {
     int64_t pushes;          /* P: (node, level) pushes        -- graph.h:94 branch taken        */
     int64_t edges;           /* E: sum of deg over the pushes  -- graph.h:96-99 iterations       */
     int64_t filled;          /* output slots written (v > 0)   -- graph.h:121                    */
-    int64_t support;         /* sum over rows of reserve-map size -- graph.h:111                 */
+    int64_t support;         /* sum over rows of reserve-map size -- graph.h:111 (exact with option exact_stats=1) */
     int64_t frontier;        /* sum over rows and levels of frontier size                        */
     int64_t lds_levels;      /* levels whose residue table lived in LDS                          */
     int64_t global_levels;   /* levels whose residue table lived in the per-workgroup HBM table  */
@@ -128,6 +128,9 @@ int gp_reset_stats(gp_graph* g);
  *   "max_workgroups"  upper bound on persistent workgroups (0 = CUs x resident blocks)
  *   "workspace_mb"    HBM scratch budget in MiB (default 65536)
  *   "force_global"    1 = never use the LDS residue table (testing the HBM-table path)
+ *   "exact_stats"     1 = always aggregate the whole reserve map, so that gp_stats.support is the
+ *                      exact sum of reserve-map sizes (default 0: nodes that provably cannot
+ *                      reach the top-K are never tabled and `support` counts only tabled nodes)
  * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.
  */
 int gp_set_option(gp_graph* g, const char* key, int64_t value);

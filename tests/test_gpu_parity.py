@@ -74,7 +74,10 @@ def test_synthetic_small(mode, order, alpha, rmax, K, force_global):
     indptr, indices = synth.shape_csr("small")
     seeds = synth.seeds(len(indptr) - 1, 512)
     coef = make_coef(mode, order, alpha)
-    got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"force_global": force_global})
+    got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"force_global": force_global, "exact_stats": 1})
+    got2, st2 = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"force_global": force_global})
+    _assert_parity(seeds, K, got2, got)          # pruned aggregation selects the same rows
+    assert st2["pushes"] == st["pushes"] and st2["filled"] == st["filled"] and st2["support"] <= st["support"]
     exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
     _assert_parity(seeds, K, got, exp)
     assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"]
@@ -192,7 +195,8 @@ def test_partitioned_levels_small_lds():
     r = RECIPES[("reddit", "avg")]
     base, st0 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, r.top_k)
     small, st1 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, r.top_k,
-                          options={"block_threads": 256, "lds_bytes": 40960})
+                          options={"block_threads": 256, "lds_bytes": 40960, "exact_stats": 1})
+    base, st0 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, r.top_k, options={"exact_stats": 1})
     exp, _ = _oracle(indptr, indices, seeds, r.coef(), r.rmax, r.top_k)
     _assert_parity(seeds, r.top_k, base, exp)
     _assert_parity(seeds, r.top_k, small, exp)

@@ -62,15 +62,22 @@ struct PushEntry { int start; int len; double share; };  // 16 B
 struct ResRec    { int key;   int pad; double val; };    // 16 B  residue table record (HBM)
 struct Cand      { u64 bits;  int key; int pad;  };      // 16 B  top-K candidate
 
+// Per-level counters produced by SCAN for the next EXPAND.  Double-buffered by level parity so
+// that resetting one set never races with threads still reading the other (no extra barriers).
+struct LevelCtr {
+    double dangling;      // mass returned to the seed by dangling nodes
+    u32 n_dangling;       // how many dangling nodes were drained
+    u32 n_push;           // SHORT push-list entries (range length <= kLongLen), growing from the front
+    u32 n_long;           // LONG entries (chunks of <= kSplitLen), growing from the back of the same buffer
+    u32 e_short;          // edges covered by the short entries
+    u32 e_next;           // all edges the next EXPAND will traverse
+    u32 pad;
+};
+
 // Control block (lives in LDS, one per workgroup).
 struct Ctl {
     long long row;        // row index pulled from the queue
-    double dangling;      // mass returned to the seed by dangling nodes this level
-    u32 n_dangling;       // how many dangling nodes were drained this level
-    u32 n_push;           // SHORT push-list entries of this level (range length <= kLongLen), growing from the front
-    u32 n_long;           // LONG entries (chunks of <= kSplitLen), growing from the back of the same buffer
-    u32 e_short;          // edges covered by the short entries
-    u32 e_next;           // sum of their lengths = edges the next EXPAND will traverse
+    LevelCtr lc[2];       // what SCAN of level l produces for level l+1 lives in lc[l & 1]
     u32 log_count;        // reserve-log records so far
     u32 n_cand;           // top-K candidates (value > 0)
     u32 ovf;              // an LDS table partition overflowed (recoverable: more partitions)
@@ -290,7 +297,7 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
 // Drains the residue table of one level (or one partition of it).  U slots per thread are
 // handled per round so that the indptr loads of all U nodes are in flight together.
 template <int BLOCK, bool IN_LDS, int U>
-__device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
+__device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                            ResRec* resg, u32 cap, int* log_key, double* log_val,
                                            PushEntry* push, double c, bool do_push,
                                            u64& st_push, u64& st_edges, u64& st_front)
@@ -353,8 +360,8 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkey
             if (want_deg[u]) {
                 const u32 deg = (u32)(de[u] - ds[u]);
                 if (deg == 0) {                                                      // graph.h:91-93
-                    __hip_atomic_fetch_add(&ctl->dangling, r[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&ctl->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&nx->dangling, r[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (r[u] >= p.rmax * (double)deg) {                           // graph.h:94
                     ++st_push; st_edges += deg;
                     const double sh = r[u] / (double)deg;                            // graph.h:95
@@ -371,24 +378,24 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, int* lkey
         //     front, long-range chunks from the back
         if (__ballot(e_sum != 0) == 0) continue;                  // wave-uniform: nobody pushes
         u32 pi[U];
-        wave_alloc_flags<U>(&ctl->n_push, is_short, pi, lane);
+        wave_alloc_flags<U>(&nx->n_push, is_short, pi, lane);
         u32 qi = 0;
-        if (__ballot(n_long != 0) != 0) qi = wave_alloc(&ctl->n_long, n_long, lane);   // hubs only
+        if (__ballot(n_long != 0) != 0) qi = wave_alloc(&nx->n_long, n_long, lane);   // hubs only
         if (e_sum) {
-            __hip_atomic_fetch_add(&ctl->e_next, e_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (e_short) __hip_atomic_fetch_add(&ctl->e_short, e_short, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&nx->e_next, e_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (e_short) __hip_atomic_fetch_add(&nx->e_short, e_short, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (len[u] == 0) continue;
                 if (is_short[u]) {
                     // the two lists meet in the middle at worst: total entries <= push_cap by the host bound
-                    if ((u64)pi[u] + ctl->n_long < p.push_cap) {
+                    if ((u64)pi[u] + nx->n_long < p.push_cap) {
                         PushEntry pe; pe.start = ds[u]; pe.len = len[u]; pe.share = share[u];
                         push[pi[u]] = pe;
                     } else ctl->fail = 1;
                 } else {
                     for (int off = 0; off < len[u]; off += kSplitLen) {
-                        if ((u64)qi + ctl->n_push < p.push_cap) {
+                        if ((u64)qi + nx->n_push < p.push_cap) {
                             PushEntry pe;
                             pe.start = ds[u] + off;
                             pe.len = min(kSplitLen, len[u] - off);
@@ -908,17 +915,20 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
             PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
             const u32 snap_log = ctl->log_count;          // first log record of this level
+            // Counters this level's SCAN will fill.  The other parity is what the threads have just
+            // read (previous level), this one was last read two levels ago: thread 0 may clear it
+            // now, and SCAN only starts after the end-of-EXPAND barrier.  No barrier needed here.
+            LevelCtr* nx = &ctl->lc[lvl & 1];
+            if (tid == 0) {
+                nx->dangling = 0.0; nx->n_dangling = 0; nx->n_push = 0; nx->n_long = 0;
+                nx->e_short = 0; nx->e_next = 0;
+            }
             if (!in_lds) {
                 parts = 1;
                 if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; }
                 cap = (u32)min(p.resg_cap, max((u64)kMinCap, 2 * need));
+                __syncthreads();
             }
-            __syncthreads();
-            if (tid == 0) {
-                ctl->n_push = 0; ctl->n_long = 0; ctl->e_next = 0; ctl->e_short = 0;
-                ctl->dangling = 0.0; ctl->n_dangling = 0; ctl->ovf = 0;
-            }
-            __syncthreads();
             // Hash partitions (q, P) of the level's targets, refined in place on overflow exactly
             // like the aggregation partitions of topk_row (nothing to undo: a partition is
             // scanned only after its expansion succeeded).
@@ -963,8 +973,8 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             __syncthreads();
                             continue;
                         }
-                        if (in_lds) scan_level<BLOCK, true,  4>(p, ctl, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
-                        else        scan_level<BLOCK, false, 4>(p, ctl, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
+                        if (in_lds) scan_level<BLOCK, true,  4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
+                        else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
                         if (ctl->fail) break;
@@ -978,10 +988,9 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                 if (c > 0.0 && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
             }
             if (ctl->fail || !do_push) break;
-            n_push_cur = ctl->n_push; n_long_cur = ctl->n_long; e_cur = ctl->e_next; e_short_cur = ctl->e_short;
-            dang_cur = ctl->dangling; has_dang_cur = ctl->n_dangling != 0;
+            n_push_cur = nx->n_push; n_long_cur = nx->n_long; e_cur = nx->e_next; e_short_cur = nx->e_short;
+            dang_cur = nx->dangling; has_dang_cur = nx->n_dangling != 0;
             cur ^= 1;
-            __syncthreads();                    // everyone has read the counters before they are reset
         }
         __syncthreads();
         if (ctl->fail) {

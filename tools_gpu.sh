@@ -1,5 +1,5 @@
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 run() { GRANDPLUS_DIAG=$1 timeout 900 python bench.py --workload $2 --steps 3 --warmup 1 --seeds-per-gpu 8192 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('$2 diag=$1', d['value'], 'rows/s', d['detail'].get('diag_phase_share'), d['detail'].get('diag_topk_sub_share'), d['detail'].get('diag_counts_per_row'), 'support/row', d['detail']['support_per_row'])"; }
+d=json.loads(sys.stdin.readline()); print('$2 diag=$1', d['value'], 'rows/s', d['detail'].get('diag_phase_share'), 'bt', d['detail']['block_threads'], 'wgs', d['detail']['workgroups'])"; }
 for w in mag reddit pubmed cora; do run 0 $w; run 1 $w; done

@@ -215,6 +215,8 @@ def main():
             "detail": {"pushes_per_row": round(stats["pushes"] / stats["rows"], 1),
                        "edges_per_row": round(stats["edges"] / stats["rows"], 1),
                        "support_per_row": round(stats["support"] / stats["rows"], 1),
+                       "frontier_per_row": round(stats["frontier"] / stats["rows"], 1),
+                       "degree_lookups_per_row": round(stats["degree_lookups"] / stats["rows"], 1),
                        "edge_pushes_per_s_per_gpu": round(stats["edges"] / args.steps / (avg_ms * 1e-3), 0),
                        "lds_levels": stats["lds_levels"], "global_levels": stats["global_levels"],
                        "workgroups": stats["workgroups"], "block_threads": stats["block_threads"],

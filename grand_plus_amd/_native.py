@@ -32,7 +32,7 @@ class GpStats(ctypes.Structure):
         ("rows", ctypes.c_int64), ("pushes", ctypes.c_int64), ("edges", ctypes.c_int64),
         ("filled", ctypes.c_int64), ("support", ctypes.c_int64), ("frontier", ctypes.c_int64),
         ("lds_levels", ctypes.c_int64), ("global_levels", ctypes.c_int64),
-        ("failed_rows", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
+        ("failed_rows", ctypes.c_int64), ("degree_lookups", ctypes.c_int64), ("kernel_ms", ctypes.c_double),
         ("workgroups", ctypes.c_int32), ("block_threads", ctypes.c_int32),
         ("lds_bytes", ctypes.c_int32), ("lds_slots", ctypes.c_int32),
         ("workspace_bytes", ctypes.c_int64),

@@ -54,6 +54,7 @@ struct gp_graph {
     int64_t n_nodes = 0, nnz = 0;
     int* d_indptr = nullptr; int* d_indices = nullptr;
     int no_dangling = 1;
+    int deg_shift = 31; uint32_t node_mask = 0x7FFFFFFFu, deg_sat = 0;   // packed column ids (see pack_degree_kernel)
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
@@ -231,6 +232,18 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
     if (hipMemcpy(g->d_indptr, indptr, sizeof(int) * (size_t)(n_nodes + 1), hipMemcpyHostToDevice) != hipSuccess ||
         (nnz > 0 && hipMemcpy(g->d_indices, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess))
         return cleanup(fail(GP_ERR_HIP, "CSR upload failed"));
+    {   // let the degree ride in the spare bits above the column id (sign bit stays clear)
+        int id_bits = 1;
+        while (id_bits < 31 && ((int64_t)1 << id_bits) < n_nodes) ++id_bits;
+        const int spare = 31 - id_bits;
+        if (spare >= 2 && nnz > 0) {
+            g->deg_shift = id_bits; g->node_mask = (1u << id_bits) - 1u; g->deg_sat = (1u << spare) - 1u;
+            hipLaunchKernelGGL(pack_degree_kernel, dim3(4096), dim3(256), 0, 0, g->d_indptr, g->d_indices,
+                               (long long)nnz, g->deg_shift, g->deg_sat);
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+                return cleanup(fail(GP_ERR_HIP, "degree packing kernel failed"));
+        }
+    }
     if (hipMalloc(&g->d_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
         hipHostMalloc(&g->h_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
         hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
@@ -361,6 +374,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
 
     KParams kp;
     kp.indptr = g->d_indptr; kp.indices = g->d_indices; kp.n_nodes = (int)g->n_nodes;
+    kp.deg_shift = g->deg_shift; kp.node_mask = g->node_mask; kp.deg_sat = g->deg_sat;
     kp.seeds = d_seeds; kp.n_seeds = n_seeds;
     kp.coef = g->d_coef; kp.n_coef = n_coef; kp.rmax = rmax; kp.K = K;
     kp.out_row = d_row; kp.out_col = d_col; kp.out_val = d_val; kp.out_filled = d_filled;
@@ -419,6 +433,7 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     s.lds_levels = (int64_t)g->h_counters[kLdsLevels];
     s.global_levels = (int64_t)g->h_counters[kGlobalLevels];
     s.failed_rows = (int64_t)g->h_counters[kFailedRows];
+    s.degree_lookups = (int64_t)g->h_counters[kDegLookups];
     s.diag_ticks_scan = (int64_t)g->h_counters[kTicksScan];
     s.diag_ticks_expand = (int64_t)g->h_counters[kTicksExpand];
     s.diag_ticks_topk = (int64_t)g->h_counters[kTicksTopk];

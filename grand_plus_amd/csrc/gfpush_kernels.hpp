@@ -90,7 +90,7 @@ struct Ctl {
 };
 
 enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
-               kGlobalLevels, kFailedRows,
+               kGlobalLevels, kFailedRows, kDegLookups,
                kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
                kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
                kNumCounters };
@@ -121,6 +121,9 @@ enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLe
 
 struct KParams {
     const int* indptr; const int* indices; int n_nodes;
+    // Device `indices` words are PACKED: column id in the low `deg_shift` bits, min(deg(column), deg_sat)
+    // above them (sign bit clear).  The degree of every push target thus arrives with its id.
+    int deg_shift; u32 node_mask; u32 deg_sat;
     const int* seeds; long long n_seeds;
     const double* coef; int n_coef; double rmax; int K;
     int* out_row; int* out_col; double* out_val; int* out_filled;
@@ -300,7 +303,7 @@ template <int BLOCK, bool IN_LDS, int U>
 __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                            ResRec* resg, u32 cap, int* log_key, double* log_val,
                                            PushEntry* push, double c, bool do_push,
-                                           u64& st_push, u64& st_edges, u64& st_front)
+                                           u64& st_push, u64& st_edges, u64& st_front, u64& st_deg)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 wave_first = (u32)(tid & ~63);
@@ -330,14 +333,23 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr*
                 if (occ[u]) { st_l2(&resg[slot].key, kEmpty); st_l2(&resg[slot].val, 0.0); }
             }
         }
-        // (b) issue the degree loads of the round
+        // (b) degrees.  The key carries min(deg, deg_sat) of its node (packed by the host side into every
+        //     column id), so the push test needs no memory access; only nodes that DO push (they need
+        //     their CSR offset) and saturated hubs read the two indptr words.
         int ds[U], de[U]; bool want_deg[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            // deg >= 1 everywhere => a node with r < rmax can neither push nor be dangling
-            want_deg[u] = occ[u] && do_push && (r[u] >= p.rmax || !p.no_dangling);
-            ds[u] = 0; de[u] = 0;
-            if (want_deg[u]) { ds[u] = p.indptr[k[u]]; de[u] = p.indptr[k[u] + 1]; }       // graph.h:43-45
+            want_deg[u] = false; ds[u] = 0; de[u] = 0;
+            if (occ[u] && do_push) {
+                const u32 dq = (u32)k[u] >> p.deg_shift;
+                // exact degree known and the test fails => dropped without touching memory   (graph.h:94);
+                // a saturated field still says deg >= deg_sat, so r < rmax*deg_sat cannot push either
+                if (dq == 0u || r[u] >= p.rmax * (double)dq) {
+                    const int node = (int)((u32)k[u] & p.node_mask);
+                    want_deg[u] = true;
+                    ds[u] = p.indptr[node]; de[u] = p.indptr[node + 1]; ++st_deg;           // graph.h:43-45
+                }
+            }
         }
         // (c) reserve log: one (node, coef*r) record per frontier node          graph.h:90 / :109
         u32 li[U];
@@ -573,7 +585,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                 if (k != kEmpty) {
                     ++n_nodes;                                                   // graph.h:111 res.size()
                     const double v = avals[slot];
-                    if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); c.key = k; keep = true; }   // graph.h:121
+                    if (v > 0.0) { c.bits = (u64)__double_as_longlong(v); c.key = (int)((u32)k & p.node_mask); keep = true; }   // graph.h:121
                 }
             }
             const u32 ci = wave_alloc1(&ctl->n_cand, keep, lane);
@@ -621,7 +633,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                 for (int u = 0; u < 4; ++u) {
                     const u32 i = base + (u32)u * BLOCK + tid;
                     kk[u] = kEmpty; vv[u] = 0.0;
-                    if (i < n_log) { vv[u] = log_val[i]; if (vv[u] >= thr) kk[u] = log_key[i]; }
+                    if (i < n_log) { vv[u] = log_val[i]; if (vv[u] >= thr) kk[u] = log_key[i]; }   // keys of live records only
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -672,14 +684,12 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     if ((u64)n_log * 10 > (u64)CA * 6) P0 = (u32)(((u64)n_log * 6 + (u64)CA * 5 - 1) / ((u64)CA * 5));
     for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
     if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
-    // work stack: at most one pending sibling per refinement depth
-    u32 stk_p[20], stk_P[20]; int sp = 0;
-    for (u32 q = P0; q-- > 0;) {
-        // process partition (q, P0) and whatever it gets split into, depth first
-        stk_p[0] = q; stk_P[0] = P0; sp = 1;
-        while (sp > 0) {
-            --sp;
-            const u32 part = stk_p[sp], parts = stk_P[sp];
+    // Depth-first walk over the partition tree with two registers and no stack: (part, parts)
+    // is split into (2*part, 2*parts) on overflow; after a completed RIGHT child (odd part) the
+    // parent is complete too, so climb; after a completed left child go to its sibling.
+    {
+        u32 part = 0, parts = P0;
+        for (;;) {
             for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
             __syncthreads();
             GP_SUB(0); GP_SUB_COUNT(8, 1);
@@ -704,17 +714,17 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             if (ctl->ovf) {
                 __syncthreads();
                 if (tid == 0) ctl->ovf = 0;
-                if (sp + 2 <= 20 && parts < 0x40000000u) {
-                    stk_p[sp] = 2 * part + 1; stk_P[sp] = 2 * parts; ++sp;
-                    stk_p[sp] = 2 * part;     stk_P[sp] = 2 * parts; ++sp;
-                } else if (tid == 0) {
-                    ctl->fail = 1;                   // cannot happen for a sane hash; reported, not silent
-                }
-                continue;
+                if (parts < 0x20000000u) { part *= 2; parts *= 2; continue; }     // descend into the left half
+                if (tid == 0) ctl->fail = 1;         // cannot happen for a sane hash; reported, not silent
+                __syncthreads();
+                break;
             }
             emit_candidates(support);
             __syncthreads();
             GP_SUB(2);
+            while (parts > P0 && (part & 1u)) { part >>= 1; parts >>= 1; }       // right child done => parent done
+            ++part;                                                              // sibling / next top-level partition
+            if (parts == P0 && part == P0) break;
         }
     }
     }
@@ -854,7 +864,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
 
     for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
     u64 st_push = 0, st_edges = 0, st_front = 0, st_filled = 0, st_support = 0,
-        st_lds = 0, st_glb = 0, st_failed = 0;
+        st_lds = 0, st_glb = 0, st_failed = 0, st_deg = 0;
     u64 tk_scan = 0, tk_expand = 0, tk_topk = 0, tk_total = 0, t0 = 0, t1 = 0, t2 = 0, tk_begin = 0;
     u64 tk_scan_hbm = 0, tk_expand_hbm = 0; (void)tk_scan_hbm; (void)tk_expand_hbm;
     (void)tk_scan; (void)tk_expand; (void)tk_topk; (void)tk_total; (void)t0; (void)t1; (void)t2; (void)tk_begin;
@@ -882,6 +892,9 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             continue;
         }
 
+        // the seed's table key carries its degree like every packed column id
+        const u32 seed_deg = (u32)(p.indptr[seed + 1] - p.indptr[seed]);
+        const int seed_key = (int)((u32)seed | (min(seed_deg, p.deg_sat) << p.deg_shift));
         // state of the level about to be produced: its push list (built by the previous SCAN)
         u32 n_push_cur = 0, n_long_cur = 0, e_cur = 0, e_short_cur = 0;
         u32 seg_begin = 0, seg_len = 0; int n_levels = 0;     // biggest level of the reserve log (coef > 0)
@@ -933,26 +946,23 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             // like the aggregation partitions of topk_row (nothing to undo: a partition is
             // scanned only after its expansion succeeded).
             if (!ctl->fail) {
-                u32 stk_p[16], stk_P[16];
-                for (u32 q = parts; q-- > 0 && !ctl->fail;) {
-                    int sp = 1; stk_p[0] = q; stk_P[0] = parts;
-                    while (sp > 0) {
-                        --sp;
-                        const u32 part = stk_p[sp], np = stk_P[sp];
+                {
+                    u32 part = 0, np = parts;
+                    for (;;) {
                         GP_STAMP(t0);
                         if (lvl == 0) {                                      // frontier { seed : 1.0 }   graph.h:81
                             if (tid == 0) {
-                                const u32 s0 = slot_of(hash_a((u32)seed), cap);
-                                if (in_lds) { lkeys[s0] = seed; lvals[s0] = 1.0; }
-                                else { st_l2(&resg[s0].key, seed); st_l2(&resg[s0].val, 1.0); }
+                                const u32 s0 = slot_of(hash_a((u32)seed_key), cap);
+                                if (in_lds) { lkeys[s0] = seed_key; lvals[s0] = 1.0; }
+                                else { st_l2(&resg[s0].key, seed_key); st_l2(&resg[s0].val, 1.0); }
                             }
                         } else {
                             if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
                             else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
                             if (tid == 0 && has_dang_cur &&
-                                (np == 1 || slot_of(hash_b((u32)seed), np) == part)) {              // graph.h:92
-                                const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed, dang_cur)
-                                                       : res_add_hbm(resg, cap, seed, dang_cur);
+                                (np == 1 || slot_of(hash_b((u32)seed_key), np) == part)) {          // graph.h:92
+                                const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed_key, dang_cur)
+                                                       : res_add_hbm(resg, cap, seed_key, dang_cur);
                                 if (!ok) { if (in_lds) ctl->ovf = 1; else ctl->fail = 1; }
                             }
                         }
@@ -964,20 +974,19 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
                             __syncthreads();
                             if (tid == 0) ctl->ovf = 0;
-                            if (sp + 2 <= 16 && np < 0x40000000u) {
-                                stk_p[sp] = 2 * part + 1; stk_P[sp] = 2 * np; ++sp;
-                                stk_p[sp] = 2 * part;     stk_P[sp] = 2 * np; ++sp;
-                            } else if (tid == 0) {
-                                ctl->fail = 1;
-                            }
+                            if (np < 0x20000000u) { part *= 2; np *= 2; __syncthreads(); continue; }
+                            if (tid == 0) ctl->fail = 1;
                             __syncthreads();
-                            continue;
+                            break;
                         }
-                        if (in_lds) scan_level<BLOCK, true,  4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
-                        else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front);
+                        if (in_lds) scan_level<BLOCK, true,  4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
+                        else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
                         if (ctl->fail) break;
+                        while (np > parts && (part & 1u)) { part >>= 1; np >>= 1; }   // right child done => parent done
+                        ++part;
+                        if (np == parts && part == parts) break;
                     }
                 }
             }
@@ -1012,7 +1021,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
 
     // flush statistics: one atomic per counter per workgroup
     st_push = wave_sum64(st_push); st_edges = wave_sum64(st_edges); st_front = wave_sum64(st_front);
-    st_support = wave_sum64(st_support);
+    st_support = wave_sum64(st_support); st_deg = wave_sum64(st_deg);
     __syncthreads();
     u64* red = (u64*)(smem + kCtlBytes);
     if (tid < 8) red[tid] = 0;
@@ -1022,6 +1031,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
         __hip_atomic_fetch_add(&red[1], st_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&red[2], st_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&red[3], st_support, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&red[4], st_deg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     if (tid == 0) {
@@ -1029,6 +1039,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
         __hip_atomic_fetch_add(&p.counters[kEdges], red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kFrontier], red[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kSupport], red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kDegLookups], red[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kFilled], st_filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kLdsLevels], st_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kGlobalLevels], st_glb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1053,6 +1064,19 @@ __global__ void __launch_bounds__(256) init_tables_kernel(ResRec* resg, u64 n_re
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_res; i += stride) {
         ResRec r; r.key = kEmpty; r.pad = 0; r.val = 0.0; resg[i] = r;
+    }
+}
+
+// Packs min(deg(column), deg_sat) above the column id in every word of the device copy of
+// `indices` (done once per graph).  Column ids were validated on the host before upload.
+__global__ void __launch_bounds__(256) pack_degree_kernel(const int* indptr, int* indices, long long nnz,
+                                                          int deg_shift, u32 deg_sat)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += stride) {
+        const int v = indices[j];
+        const u32 d = (u32)(indptr[v + 1] - indptr[v]);
+        indices[j] = (int)((u32)v | (min(d, deg_sat) << deg_shift));
     }
 }
 

@@ -53,6 +53,7 @@ typedef struct gp_stats {
     int64_t lds_levels;      /* levels whose residue table lived in LDS                          */
     int64_t global_levels;   /* levels whose residue table lived in the per-workgroup HBM table  */
     int64_t failed_rows;     /* rows that hit a workspace bound (=> GP_ERR_OVERFLOW)             */
+    int64_t degree_lookups;  /* frontier nodes whose degree (two indptr words) had to be read    */
     double  kernel_ms;       /* HIP-event time of the LAST gfpush kernel on its stream           */
     int32_t workgroups;      /* persistent workgroups launched                                   */
     int32_t block_threads;   /* threads per workgroup                                            */

@@ -223,6 +223,15 @@ def main():
                        "lds_bytes": stats["lds_bytes"], "workspace_gb": round(stats["workspace_bytes"] / 2**30, 2),
                        "graph_gen_s": round(t_gen, 2), "csr_upload_s": round(t_upload, 3)},
         }
+        # HBM-side traffic per launch: measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes of
+        # this same command) and committed under profiles/; a bench run cannot profile itself.
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_mag_pmc_summary.json")))
+            if args.workload == prof.get("workload") and per == prof.get("seeds_per_gpu") and world == 1:
+                line["roofline"]["traffic"] = int(prof["derived"]["hbm_read_bytes_raw"] + prof["derived"]["hbm_write_bytes"])
+                line["roofline"]["traffic_source"] = "profiles/r01_mag_pmc_summary.json (rocprofv3 FETCH_SIZE+WRITE_SIZE, raw; see note there)"
+        except (OSError, KeyError, ValueError):
+            pass
         if stats.get("diag_ticks_total"):
             tot = stats["diag_ticks_total"]
             line["detail"]["diag_phase_share"] = {k: round(stats[f"diag_ticks_{k}"] / tot, 3) for k in ("scan", "expand", "topk", "scan_hbm", "expand_hbm")}

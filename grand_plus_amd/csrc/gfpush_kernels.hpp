@@ -54,7 +54,7 @@ constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
 constexpr int    kCtlBytes   = 256;     // control block at the start of dynamic LDS
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
-constexpr u32    kMaxParts   = 8;       // most hash partitions a level is expanded in before using the HBM table
+constexpr u32    kMaxParts   = 64;       // most hash partitions a level is expanded in before using the HBM table
 constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many slots reports overflow
                                         // (recoverable: the level / aggregation is redone in more partitions)
 

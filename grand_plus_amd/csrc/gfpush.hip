@@ -55,6 +55,7 @@ struct gp_graph {
     int* d_indptr = nullptr; int* d_indices = nullptr;
     int no_dangling = 1;
     int deg_shift = 31; uint32_t node_mask = 0x7FFFFFFFu, deg_sat = 0;   // packed column ids (see pack_degree_kernel)
+    bool packed = false; int max_degree_bits = 31;                        // packing happens at the first gfpush call
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
@@ -150,6 +151,24 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
     return GP_OK;
 }
 
+// Let the degree of every column ride in the spare bits above its id (sign bit stays clear).
+// Done once, lazily, so that the "max_degree_bits" option can restrict it (0 = plain column ids:
+// the path graphs with N >= 2^29 take).
+int ensure_packed(gp_graph* g, hipStream_t s) {
+    if (g->packed) return GP_OK;
+    g->packed = true;
+    int id_bits = 1;
+    while (id_bits < 31 && ((int64_t)1 << id_bits) < g->n_nodes) ++id_bits;
+    const int spare = std::min(31 - id_bits, g->max_degree_bits);
+    if (spare >= 2 && g->nnz > 0) {
+        g->deg_shift = id_bits; g->node_mask = (1u << id_bits) - 1u; g->deg_sat = (1u << spare) - 1u;
+        hipLaunchKernelGGL(pack_degree_kernel, dim3(4096), dim3(256), 0, s, g->d_indptr, g->d_indices,
+                           (long long)g->nnz, g->deg_shift, g->deg_sat);
+        HIP_TRY(hipGetLastError());
+    }
+    return GP_OK;
+}
+
 int check_call_args(const gp_graph* g, int64_t n_seeds, const double* coef, int n_coef, double rmax, int K) {
     if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
     if (!coef) return fail(GP_ERR_NULL, "coef is NULL");
@@ -232,18 +251,6 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
     if (hipMemcpy(g->d_indptr, indptr, sizeof(int) * (size_t)(n_nodes + 1), hipMemcpyHostToDevice) != hipSuccess ||
         (nnz > 0 && hipMemcpy(g->d_indices, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess))
         return cleanup(fail(GP_ERR_HIP, "CSR upload failed"));
-    {   // let the degree ride in the spare bits above the column id (sign bit stays clear)
-        int id_bits = 1;
-        while (id_bits < 31 && ((int64_t)1 << id_bits) < n_nodes) ++id_bits;
-        const int spare = 31 - id_bits;
-        if (spare >= 2 && nnz > 0) {
-            g->deg_shift = id_bits; g->node_mask = (1u << id_bits) - 1u; g->deg_sat = (1u << spare) - 1u;
-            hipLaunchKernelGGL(pack_degree_kernel, dim3(4096), dim3(256), 0, 0, g->d_indptr, g->d_indices,
-                               (long long)nnz, g->deg_shift, g->deg_sat);
-            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)
-                return cleanup(fail(GP_ERR_HIP, "degree packing kernel failed"));
-        }
-    }
     if (hipMalloc(&g->d_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
         hipHostMalloc(&g->h_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
         hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
@@ -302,6 +309,10 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         g->force_global = value ? 1 : 0;
     } else if (k == "exact_stats") {
         g->exact_stats = value ? 1 : 0;
+    } else if (k == "max_degree_bits") {
+        if (g->packed) return fail(GP_ERR_INVALID_ARG, "max_degree_bits must be set before the first gfpush call");
+        if (value < 0 || value > 31) return fail(GP_ERR_INVALID_ARG, "max_degree_bits must be in [0, 31]");
+        g->max_degree_bits = (int)value;
     } else {
         return fail(GP_ERR_INVALID_ARG, "unknown option '%s'", key);
     }
@@ -349,6 +360,8 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     if (g->max_workgroups > 0) n_wg = std::min(n_wg, g->max_workgroups);
     n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(n_wg, n_seeds));
     rc = ensure_workspace(g, n_coef, rmax, n_wg);
+    if (rc) return rc;
+    rc = ensure_packed(g, s);
     if (rc) return rc;
     Workspace& w = g->ws;
     n_wg = std::min(n_wg, w.n_wg);

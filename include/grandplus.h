@@ -129,6 +129,8 @@ int gp_reset_stats(gp_graph* g);
  *   "max_workgroups"  upper bound on persistent workgroups (0 = CUs x resident blocks)
  *   "workspace_mb"    HBM scratch budget in MiB (default 65536)
  *   "force_global"    1 = never use the LDS residue table (testing the HBM-table path)
+ *   "max_degree_bits" cap on the spare column-id bits used to carry degrees (0 = none; testing the
+ *                      path taken by graphs with N >= 2^29); only before the first gfpush call
  *   "exact_stats"     1 = always aggregate the whole reserve map, so that gp_stats.support is the
  *                      exact sum of reserve-map sizes (default 0: nodes that provably cannot
  *                      reach the top-K are never tabled and `support` counts only tabled nodes)

@@ -259,3 +259,41 @@ def test_reddit_shape_properties():
     # idempotence: a second call on the same graph object gives the same index sets
     again, _ = _run_gpu(indptr, indices, seeds[:512], r.coef(), r.rmax, K)
     _assert_parity(seeds[:512], K, again, (got[0][:512 * K], got[1][:512 * K], got[2][:512 * K]))
+
+
+@pytest.mark.parametrize("bits", [0, 2, 5])
+def test_degree_field_widths(bits):
+    """Column ids carry min(deg, 2^bits-1) in their spare high bits.  bits=0 is the plain-id path that
+    graphs with N >= 2^29 take; small widths saturate often (hubs fall back to the indptr lookup)."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import RECIPES
+    indptr, indices = synth.shape_csr("small")
+    seeds = synth.seeds(len(indptr) - 1, 300)
+    r = RECIPES[("mag", "ppr")]
+    got, st = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, r.top_k, options={"max_degree_bits": bits, "exact_stats": 1})
+    exp, ost = _oracle(indptr, indices, seeds, r.coef(), r.rmax, r.top_k)
+    _assert_parity(seeds, r.top_k, got, exp)
+    assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"] and st["support"] == ost["support_sum"]
+    assert st["degree_lookups"] >= st["pushes"]              # every pushing node reads its CSR offset
+    if bits == 0:
+        assert st["degree_lookups"] > 5 * st["pushes"]       # plain ids: (almost) every frontier node looks its degree up
+
+
+def test_dangling_nodes_with_packed_degrees():
+    """Directed graph with many dangling nodes (degree field 0): their mass returns to the seed."""
+    rng = np.random.default_rng(7)
+    n = 500
+    rows = []
+    for u in range(n):
+        deg = 0 if u % 3 == 0 else int(rng.integers(1, 9))
+        rows.append(np.sort(rng.choice(n, size=deg, replace=False)))
+    indptr = np.zeros(n + 1, np.int32); indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows).astype(np.int32)
+    seeds = np.arange(0, n, 3 if n % 2 else 2)[:120]
+    seeds = np.concatenate([seeds, np.arange(1, 120, 2)])
+    from grand_plus_amd.recipes import make_coef
+    coef = make_coef("ppr", 6, 0.15)
+    got, st = _run_gpu(indptr, indices, seeds, coef, 1e-6, 16)
+    exp, ost = _oracle(indptr, indices, seeds, coef, 1e-6, 16)
+    _assert_parity(seeds, 16, got, exp)
+    assert ost["dangling"] > 0 and st["pushes"] == ost["pushes"]

@@ -91,9 +91,9 @@ def cpu_baseline(indptr, indices, seeds, recipe, budget_s: float = 12.0):
             t = time.perf_counter()
             g.gfpush_omp(sample, row, col, val, coef, recipe.rmax, K)
             rbest = max(rbest, n / (time.perf_counter() - t))
-        out = {"value": round(rbest, 1), "unit": "rows/s", "cores": cores, "kind": "reference",
+        out = {"value": round(rbest, 1), "unit": "rows/s", "cores": 40, "host_cores": cores, "kind": "reference",
                "sample": f"{n} seeds of the same workload, reference precompute/propagation.cpp compiled as oracle/_ref, 40 OpenMP threads as shipped (graph.h:41) on {cores} cores, best of 2",
-               "port_value": round(best, 1)}
+               "port_value": round(best, 1), "port_cores": cores}
     return out
 
 

@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+timeout 900 python bench.py 2>/dev/null | tail -1

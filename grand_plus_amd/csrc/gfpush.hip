@@ -53,7 +53,6 @@ struct gp_graph {
     int device = 0;
     int64_t n_nodes = 0, nnz = 0;
     int* d_indptr = nullptr; int* d_indices = nullptr;
-    int no_dangling = 1;
     int deg_shift = 31; uint32_t node_mask = 0x7FFFFFFFu, deg_sat = 0;   // packed column ids (see pack_degree_kernel)
     bool packed = false; int max_degree_bits = 31;                        // packing happens at the first gfpush call
     int num_cus = 0;
@@ -226,11 +225,10 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
     for (int64_t i = 0; i < n_nodes; ++i)
         if (indptr[i + 1] < indptr[i]) return fail(GP_ERR_INVALID_CSR, "indptr decreases at node %lld", (long long)i);
     if (indptr[n_nodes] != nnz) return fail(GP_ERR_INVALID_CSR, "indptr[n] = %d but nnz = %lld", indptr[n_nodes], (long long)nnz);
-    int bad = 0, has_dangling = 0;
+    int bad = 0;
 #pragma omp parallel for reduction(| : bad)
     for (int64_t j = 0; j < nnz; ++j) bad |= (indices[j] < 0 || indices[j] >= n_nodes);
     if (bad) return fail(GP_ERR_INVALID_CSR, "a column id is outside [0, %lld)", (long long)n_nodes);
-    for (int64_t i = 0; i < n_nodes; ++i) has_dangling |= (indptr[i + 1] == indptr[i]);
 
     const int ndev = gp_device_count();
     if (ndev <= 0) return fail(GP_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
@@ -241,7 +239,7 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
 
     gp_graph* g = new (std::nothrow) gp_graph();
     if (!g) return fail(GP_ERR_NOMEM, "host allocation failed");
-    g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->no_dangling = has_dangling ? 0 : 1;
+    g->device = device; g->n_nodes = n_nodes; g->nnz = nnz;
     g->num_cus = prop.multiProcessorCount;
     int rc = GP_OK;
     auto cleanup = [&](int status) { gp_graph_destroy(g); return status; };
@@ -397,7 +395,6 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.cand = w.cand; kp.cand_cap = w.cand_cap;
     kp.counters = g->d_counters;
     kp.lds_slots = lds_slots;
-    kp.no_dangling = g->no_dangling;
     kp.force_global = g->force_global;
     kp.prune = g->exact_stats ? 0 : 1;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0

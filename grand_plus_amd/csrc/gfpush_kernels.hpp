@@ -1,42 +1,43 @@
 // gfpush_kernels.hpp -- hand-written HIP (gfx950 / CDNA4) kernels for GFPush.
 //
-// One persistent 64-lane-wave workgroup owns one seed ("row") at a time and pulls rows
-// from a device-side queue (the reference's `omp parallel for schedule(dynamic)` over
+// One persistent workgroup (16 wave64 by default) owns one seed ("row") at a time and pulls
+// rows from a device-side queue (the reference's `omp parallel for schedule(dynamic)` over
 // seeds, precompute/graph.h:73-74).  Per row it runs the level-synchronous push of
 // graph.h:83-110 and the top-K of graph.h:111-126:
 //
-//   SCAN    walk the residue table of this level; for every node u with residue r:
-//             reserve[u] += coef[lvl] * r                        (graph.h:90 / :109)
-//             deg==0        -> r returns to the seed             (graph.h:91-93)
-//             r >= rmax*deg -> append (CSR range, r/deg) to the push list  (graph.h:94-95)
-//             else          -> r is dropped                      (no else branch)
-//           clearing each slot as it goes; wave-level prefix sums compact the push list.
 //   EXPAND  stream the CSR neighbour ranges of the push list (coalesced within a range)
-//           and add r/deg into the NEXT level's residue table    (graph.h:96-99).
-//   TOPK    radix-select the K largest reserve values (value desc, column asc) and
-//           write row/col/value at slot row*K+rank                (graph.h:111-126).
+//           and add r/deg into the level's residue table          (graph.h:96-99).
+//   SCAN    drain that table; for every node u with residue r:
+//             reserve[u] += coef[lvl] * r   -> one (u, coef*r) record in the reserve LOG   (graph.h:90 / :109)
+//             deg==0        -> r returns to the seed             (graph.h:91-93)
+//             r >= rmax*deg -> append (CSR range, r/deg) to the next push list  (graph.h:94-95)
+//             else          -> r is dropped                      (no else branch)
+//           ballot + mbcnt prefix sums compact the log and the push lists.
+//   TOPK    sum the log per node in an LDS table (only nodes that can reach the top-K are
+//           tabled), radix-select the K largest (value desc, column asc) and write
+//           row/col/value at slot row*K+rank                      (graph.h:111-126).
 //
-// Residue table of a level: an open-addressing hash table {node -> residue}.  It lives in
-// LDS (keys int32 + values fp64, 12 B/slot) whenever the level's edge count guarantees it
-// fits (edges <= 0.7 * slots), otherwise in a per-workgroup table in HBM/L2 (16-B records).
+// Residue table of a level: an open-addressing hash table {node -> fp64 residue} in LDS
+// (keys int32 + values fp64, 12 B/slot).  A level whose edge count (an upper bound on its
+// distinct targets) exceeds 0.75 * slots is expanded in P hash PARTITIONS: pass p re-reads the
+// (L2-hot) CSR ranges and keeps only targets with part(v) == p, so the table never leaves LDS
+// and no global atomic is issued; a partition that still overflows is split in two in place.
+// Only levels needing more than kMaxParts passes use a per-workgroup table in HBM/L2.
+//
+// Table keys are the PACKED column ids of the device CSR: node id in the low bits and
+// min(deg(node), deg_sat) in the spare bits above it (pack_degree_kernel, once per graph).
+// The push test therefore needs no memory access; only nodes that do push read indptr.
+//
 // Residues are fp64 end to end, as in the reference (graph.h:76-77,95): the share r/deg is the
 // reference's own fp64 quotient and the push test `r >= rmax*deg` (graph.h:94) sees the same
 // number whenever a node has a single contribution -- which is what makes exact rational
 // ties such as 1/deg(seed) == rmax*deg(u) fall the way the reference decides them.  Sums of
-// several contributions use native fp64 atomic adds (ds_add_f64 / global_atomic_add_f64),
-// so their last bits depend on arrival order exactly as the reference's depend on its
-// hash-map iteration order.  Reserve values see one add per node per level, in level order.
-//
-// A level too large for one LDS table is expanded in P hash PARTITIONS: pass p re-reads the
-// (L2-hot) CSR ranges and keeps only targets with part(v) == p, so the table never leaves
-// LDS and no global atomic is issued; only levels needing more than kMaxParts passes use the
-// HBM table.
+// several contributions use native fp64 atomic adds (ds_add_f64), so their last bits depend
+// on arrival order exactly as the reference's depend on its hash-map iteration order.
 //
 // Reserve map of a row: NOT a table while the row runs.  SCAN appends one (node, coef*r)
-// record per frontier node to a per-workgroup LOG (coalesced streaming stores).  At the end
-// of the row the log is summed per node in an LDS hash table (in key partitions when the log
-// is long) whose occupied slots are the top-K candidates.  This replaces ~8 random 64-B
-// accesses per frontier node by 12 streamed bytes.
+// record per frontier node to a per-workgroup LOG (coalesced streaming stores); TOPK sums it.
+// This replaced ~8 random 64-B accesses per frontier node by 12 streamed bytes.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -54,7 +55,7 @@ constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
 constexpr int    kCtlBytes   = 256;     // control block at the start of dynamic LDS
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
-constexpr u32    kMaxParts   = 64;       // most hash partitions a level is expanded in before using the HBM table
+constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
 constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many slots reports overflow
                                         // (recoverable: the level / aggregation is redone in more partitions)
 
@@ -133,7 +134,6 @@ struct KParams {
     Cand* cand;      u64 cand_cap;       // per-workgroup top-K candidates
     u64* counters;
     u32 lds_slots;
-    int no_dangling;                      // 1 when every node has degree >= 1
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
 };

@@ -45,7 +45,7 @@ def load_graph(source: str, threads: int):
     from grand_plus_amd import synth
     kind, name = source.split(":")
     if kind == "synth":
-        os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+        synth.set_threads(threads)                 # world ranks generate the same graph concurrently
         return synth.shape_csr(name)
     z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
     return z["indptr"], z["indices"]

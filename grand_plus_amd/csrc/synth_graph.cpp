@@ -134,6 +134,10 @@ int gp_synth_powerlaw_csr(int64_t n_nodes, int64_t n_samples, uint64_t seed, int
 
 void gp_synth_free(void* p) { free(p); }
 
+// Threads used by gp_synth_powerlaw_csr (0 = OpenMP default).  Explicit because several ranks of one
+// node generate the same graph at once and OMP_NUM_THREADS is read before Python can set it.
+void gp_synth_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+
 // S distinct seed nodes: an affine walk over 0..n-1 (a seeded permutation prefix).
 int gp_synth_seeds(int64_t n_nodes, int64_t n_seeds, uint64_t seed, int32_t* out)
 {

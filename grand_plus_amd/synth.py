@@ -32,6 +32,8 @@ def _lib():
         lib.gp_synth_seeds.restype = ctypes.c_int
         lib.gp_synth_seeds.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_int32)]
+        lib.gp_synth_set_threads.restype = None
+        lib.gp_synth_set_threads.argtypes = [ctypes.c_int]
         lib.gp_checksum64.restype = ctypes.c_uint64
         lib.gp_checksum64.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         _LIB = lib
@@ -57,6 +59,11 @@ SHAPES = {
     "amazon2m":  Shape("amazon2m", 2_449_029, 30_750_000),
     "mag":       Shape("mag", 12_400_000, 86_850_000),
 }
+
+
+def set_threads(n: int) -> None:
+    """Host threads the generator may use (several ranks of one node generate at once)."""
+    _lib().gp_synth_set_threads(int(n))
 
 
 def powerlaw_csr(n_nodes: int, samples: int, seed: int = 42, offset: int = 10):

@@ -23,7 +23,7 @@ EXPORTS = (
     "gp_abi_version", "gp_strerror", "gp_last_error", "gp_device_count",
     "gp_graph_create", "gp_graph_destroy", "gp_graph_num_nodes", "gp_graph_nnz",
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
-    "gp_set_option",
+    "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
 )
 
 
@@ -60,6 +60,14 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.  If this library were loaded first it
+    # would pull in /opt/rocm's copies and the process would hold TWO HIP runtimes; whichever initialises
+    # second can then report "no ROCm-capable device".  Loading torch first makes the dynamic loader bind
+    # libgrandplus.so to the runtime torch already mapped, so device pointers and streams are shared.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     i32p, f64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)
     vp = ctypes.c_void_p
@@ -90,6 +98,12 @@ def lib():
     L.gp_get_stats.argtypes = [vp, ctypes.POINTER(GpStats)]
     L.gp_reset_stats.restype = ctypes.c_int
     L.gp_reset_stats.argtypes = [vp]
+    L.gp_random_prop_rows.restype = ctypes.c_int
+    L.gp_random_prop_rows.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, ctypes.c_int32,
+                                      vp, ctypes.c_int32, ctypes.c_float, ctypes.c_int, ctypes.c_uint64, vp, vp, vp]
+    L.gp_random_prop_coo.restype = ctypes.c_int
+    L.gp_random_prop_coo.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, ctypes.c_int64,
+                                     ctypes.c_float, ctypes.c_int, ctypes.c_uint64, vp, vp, vp]
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     if L.gp_abi_version() != 1:

@@ -204,6 +204,10 @@ const char* gp_strerror(int status) {
 
 const char* gp_last_error(void) { return g_last_error.c_str(); }
 
+void gp_internal_set_error(int status, const char* where, const char* detail) {
+    (void)fail(status, "%s: %s", where ? where : "", detail ? detail : "");
+}
+
 int gp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -138,6 +138,40 @@ int gp_reset_stats(gp_graph* g);
  */
 int gp_set_option(gp_graph* g, const char* key, int64_t value);
 
+/* ------------------------------------------------------------------------------------------
+ * Next row of the scope table: GRAND+'s feature augmentation
+ * ("random propagation"), reference Grand_Plus.random_prop (model.py:80-87, model_mag.py:80-86):
+ * DropNode on the scores, weighted segment-sum of neighbour features, divide by
+ * (sum of kept scores + 1e-12).  fp32 like the reference.  All pointers are DEVICE pointers on
+ * `device`; the launch is asynchronous on `stream`.
+ *
+ * `training` != 0 applies dropout with rate `dropnode_rate`: kept scores are scaled by
+ * 1/(1-rate) (model.py:82).  The keep decision of entry e is d_keep[e] != 0 when d_keep is
+ * given (parity tests), otherwise a counter-based RNG of (seed, e) -- change `seed` every call.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Fused form: consumes the [S x K] rows gfpush left on the device.  Output row b is built from
+ * matrix row r = d_batch_rows[b] (r = b when d_batch_rows is NULL), using its first d_filled[r]
+ * slots (all K when d_filled is NULL): out[b,:] = sum_k w_k X[col[r,k],:] / (sum_k w_k + 1e-12),
+ * w_k = (float)val[r,k] * keep_k/(1-rate).  Replaces the caller-side slicing, feature gather and
+ * upload of model.py:310-316 together with random_prop itself.  d_x is X[n_nodes x feat_dim]. */
+int gp_random_prop_rows(int device, const float* d_x, int64_t n_nodes, int32_t feat_dim,
+                        const int32_t* d_col, const double* d_val, const int32_t* d_filled, int32_t K,
+                        const int32_t* d_batch_rows, int32_t n_batch,
+                        float dropnode_rate, int training, uint64_t seed, const uint8_t* d_keep,
+                        float* d_out, void* stream);
+
+/* Reference-shaped form: feats[n_entries x feat_dim] already gathered, scores[n_entries],
+ * idx[n_entries] sorted ascending (the row-major order of scipy's .nonzero(), model.py:312);
+ * out[n_out x feat_dim] with n_out = idx[-1] + 1 (model.py:84). */
+int gp_random_prop_coo(int device, const float* d_feats, int64_t n_entries, int32_t feat_dim,
+                       const float* d_scores, const int64_t* d_idx, int64_t n_out,
+                       float dropnode_rate, int training, uint64_t seed, const uint8_t* d_keep,
+                       float* d_out, void* stream);
+
+/* internal: lets the second translation unit report through gp_last_error (not for callers) */
+void gp_internal_set_error(int status, const char* where, const char* detail);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,35 @@ class Graph:
             row.data_ptr(), col.data_ptr(), val.data_ptr(), filled.data_ptr(), ctypes.c_void_p(stream)))
         return row, col, val, filled
 
+    # -- exact inference propagation ----------------------------------
+    def propagate_features(self, features, prop_mode, order, alpha=0.2, edge_weight=None, out=None, stream=None):
+        """Exact full-graph propagation of `predict()` (`model.py:186-210`) on this graph's CSR.
+
+        features: float32 CUDA tensor [N, F]; prop_mode 'ppr' | 'avg' | 'single' (`args.prop_mode`);
+        order = `args.order`; edge_weight: float32 CUDA tensor [nnz] with the stored values of adj + I, or
+        None when they are all ones (every shipped dataset).  Returns the float32 [N, F] matrix the reference
+        feeds to the MLP (`model.py:212-213`)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if features.device != dev or features.dtype != torch.float32 or not features.is_contiguous() or features.dim() != 2:
+            raise TypeError(f"features must be a contiguous float32 [N, F] tensor on {dev}")
+        if features.shape[0] != self.num_nodes:
+            raise ValueError("features must have one row per node")
+        modes = {"ppr": 0, "avg": 1, "single": 2}
+        if prop_mode not in modes:
+            raise ValueError(f"Unknown propagation mode: {prop_mode}")            # model.py:210
+        if edge_weight is not None and (edge_weight.device != dev or edge_weight.dtype != torch.float32
+                                        or not edge_weight.is_contiguous() or edge_weight.numel() != self.nnz):
+            raise TypeError("edge_weight must be a contiguous float32 [nnz] tensor on the graph's device")
+        if out is None:
+            out = torch.empty_like(features)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _native.raise_for_status(_native.lib().gp_propagate_features(
+            self._h, features.data_ptr(), features.shape[1], edge_weight.data_ptr() if edge_weight is not None else None,
+            modes[prop_mode], int(order), float(alpha), out.data_ptr(), ctypes.c_void_p(stream)))
+        return out
+
     def reset_stats(self):
         _native.raise_for_status(_native.lib().gp_reset_stats(self._h))
 

@@ -204,6 +204,15 @@ const char* gp_strerror(int status) {
 
 const char* gp_last_error(void) { return g_last_error.c_str(); }
 
+int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indices, uint32_t* node_mask, void* stream) {
+    if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    int rc = ensure_packed(g, (hipStream_t)stream);
+    if (rc) return rc;
+    *d_indptr = g->d_indptr; *d_indices = g->d_indices; *node_mask = g->node_mask;
+    return GP_OK;
+}
+
 void gp_internal_set_error(int status, const char* where, const char* detail) {
     (void)fail(status, "%s: %s", where ? where : "", detail ? detail : "");
 }

@@ -169,6 +169,23 @@ int gp_random_prop_coo(int device, const float* d_feats, int64_t n_entries, int3
                        float dropnode_rate, int training, uint64_t seed, const uint8_t* d_keep,
                        float* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * exact full-graph feature propagation of the inference path, reference
+ * predict() (model.py:181-224), lines 186-210.  mode 0 = ppr, 1 = avg, 2 = single (args.prop_mode);
+ * `order` = args.order propagation steps.  A is the CSR of `g` (adj + I as the caller built it,
+ * model.py:243); d_edge_weight = its stored values (float32[nnz], device) or NULL for an all-ones
+ * matrix -- what adj + I is for every shipped dataset.  d_features / d_out are float32[n_nodes x
+ * feat_dim] on g's device (the reference iterates in float64 and casts the result to float32,
+ * model.py:175; here sums are fp64, storage fp32).  Enqueued on `stream`; one host synchronisation
+ * happens inside (long-row census).
+ * ------------------------------------------------------------------------------------------ */
+int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim, const float* d_edge_weight,
+                          int mode, int order, double alpha, float* d_out, void* stream);
+
+/* internal: the device CSR of a graph for the other translation units (indices words carry degree bits
+ * above *node_mask; packs them first if that has not happened yet) */
+int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indices, uint32_t* node_mask, void* stream);
+
 /* internal: lets the second translation unit report through gp_last_error (not for callers) */
 void gp_internal_set_error(int status, const char* where, const char* detail);
 

@@ -1,0 +1,71 @@
+"""Parity of gp_propagate_features with the scipy float64 restatement of the
+reference's predict() propagation.  Storage is fp32 (rounded once per step, fp64 sums): tolerance
+|d| <= 2e-6*|ref| + 1e-6*max|ref| for up to 20 steps."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _check(indptr, indices, F, mode, order, alpha, weights=None, seed=0):
+    import scipy.sparse as sp
+    import torch
+    from grand_plus_amd import Graph
+    from oracle.predict_ref import propagate_ref
+    n = len(indptr) - 1
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    data = np.ones(len(indices)) if weights is None else weights.astype(np.float64)
+    adj = sp.csr_matrix((data, indices, indptr), shape=(n, n))
+    ref = propagate_ref(adj, X, mode, order, alpha)
+    g = Graph(indptr, indices, 0)
+    w = None if weights is None else torch.from_numpy(weights.astype(np.float32)).cuda()
+    got = g.propagate_features(torch.from_numpy(X).cuda(), mode, order, alpha, edge_weight=w).cpu().numpy()
+    tol = 2e-6 * np.abs(ref) + 1e-6 * np.abs(ref).max()
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{bad.sum()} of {bad.size} elements off; max abs err {np.abs(got - ref).max():.3e}"
+    return g
+
+
+@pytest.mark.parametrize("name,mode,order,alpha", [("cora", "ppr", 20, 0.2), ("cora", "avg", 4, 0.2), ("cora", "single", 2, 0.2),
+                                                    ("pubmed", "ppr", 6, 0.5), ("citeseer", "avg", 2, 0.4)])
+def test_citation_graphs(name, mode, order, alpha):
+    z = np.load(os.path.join(GOLD, f"{name}.npz"))           # the adj + I CSR the reference's loader produces
+    _check(z["indptr"], z["indices"], 96, mode, order, alpha)
+
+
+@pytest.mark.parametrize("F", [1, 64, 100, 130])
+def test_feature_widths_and_hubs(F):
+    from grand_plus_amd import synth
+    indptr, indices = synth.shape_csr("reddit")              # max degree 19k: exercises the long-row kernel
+    _check(indptr, indices, F, "ppr", 3, 0.1, seed=F)
+
+
+def test_weighted_edges_and_dangling_rows():
+    rng = np.random.default_rng(3)
+    n = 3000
+    rows = [np.sort(rng.choice(n, size=(0 if u % 7 == 0 else int(rng.integers(1, 12))), replace=False)) for u in range(n)]
+    indptr = np.zeros(n + 1, np.int32); indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows).astype(np.int32)
+    w = rng.uniform(0.5, 2.0, size=len(indices))             # e.g. a diagonal stored as 2.0 when adj already had the loop
+    for mode in ("ppr", "avg", "single"):
+        _check(indptr, indices, 40, mode, 5, 0.3, weights=w)
+
+
+def test_order_zero_and_errors():
+    import torch
+    from grand_plus_amd import synth
+    indptr, indices = synth.shape_csr("tiny")
+    g = _check(indptr, indices, 32, "ppr", 0, 0.2)            # order 0: alpha * F
+    _check(indptr, indices, 32, "avg", 0, 0.2)
+    x = torch.zeros((len(indptr) - 1, 8), device="cuda")
+    with pytest.raises(ValueError, match="Unknown propagation mode"):
+        g.propagate_features(x, "heat", 2)
+    with pytest.raises(ValueError):
+        g.propagate_features(x[:5].contiguous(), "ppr", 2)
+    with pytest.raises(TypeError):
+        g.propagate_features(x.double(), "ppr", 2)

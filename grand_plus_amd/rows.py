@@ -1,0 +1,95 @@
+"""Device-resident propagation-matrix rows and their hand-off to the consumers of the reference.
+
+SURVEY.md 8(f) next-3: the reference turns the flat outputs into a scipy CSR (`model.py:270-272`) and, every
+training / validation step, slices it on the CPU, takes `.nonzero()`, gathers features on the host and uploads
+them (`model.py:310-316`, `model.py:147-151`).  `RowMatrix` keeps the `[S x K]` ELL rows where GFPush wrote
+them (HBM) together with the seed list; `batch_positions` maps a batch of node ids to row positions so that
+`augment.random_prop_rows` consumes the rows in place, and `to_scipy()` reproduces `topk_adj` exactly for code
+that still wants it.
+
+SURVEY.md 8(f) next-4: the reference recomputes the matrix for every (seed1, seed2) run
+(`run_model.py:83-90`).  `RowMatrix.cached(...)` stores the rows on disk keyed by a checksum of
+(CSR, seeds, coef, rmax, K) and reloads them instead of recomputing.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+
+import numpy as np
+
+
+class RowMatrix:
+    """Top-K rows of the propagation matrix for a list of seed nodes, resident on one GPU."""
+
+    def __init__(self, seeds, K, row, col, val, filled, n_nodes):
+        self.seeds = np.asarray(seeds, dtype=np.int64)       # node id of row position i
+        self.K = int(K)
+        self.row, self.col, self.val, self.filled = row, col, val, filled     # torch CUDA tensors
+        self.n_nodes = int(n_nodes)
+        self._pos = None
+
+    # ---- construction ------------------------------------------------------------------
+    @classmethod
+    def compute(cls, graph, seeds, coef, rmax, K):
+        """Run GFPush for `seeds` on `graph` (grand_plus_amd.Graph) and keep the rows on its GPU."""
+        import torch
+        s32 = np.ascontiguousarray(np.asarray(seeds), dtype=np.int32)
+        d_seeds = torch.from_numpy(s32).to(torch.device("cuda", graph.device))
+        row, col, val, filled = graph.gfpush_device(d_seeds, coef, rmax, K)
+        graph.stats()                                   # waits; raises if a row could not be computed
+        return cls(seeds, K, row, col, val, filled, graph.num_nodes)
+
+    @staticmethod
+    def cache_key(indptr, indices, seeds, coef, rmax, K) -> str:
+        h = hashlib.sha256()
+        for a in (np.ascontiguousarray(indptr, dtype=np.int32), np.ascontiguousarray(indices, dtype=np.int32),
+                  np.ascontiguousarray(seeds, dtype=np.int64), np.ascontiguousarray(coef, dtype=np.float64)):
+            h.update(str(a.shape).encode()); h.update(a.tobytes())
+        h.update(np.float64(rmax).tobytes()); h.update(np.int64(K).tobytes())
+        return h.hexdigest()[:32]
+
+    @classmethod
+    def cached(cls, cache_dir, graph, indptr, indices, seeds, coef, rmax, K):
+        """Load the rows from `cache_dir` if this exact precompute was done before, else compute and store.
+        Returns (RowMatrix, was_cached)."""
+        import torch
+        os.makedirs(cache_dir, exist_ok=True)
+        path = os.path.join(cache_dir, f"gfpush_{cls.cache_key(indptr, indices, seeds, coef, rmax, K)}.npz")
+        dev = torch.device("cuda", graph.device)
+        if os.path.exists(path):
+            z = np.load(path)
+            return cls(z["seeds"], int(z["K"]), torch.from_numpy(z["row"]).to(dev), torch.from_numpy(z["col"]).to(dev),
+                       torch.from_numpy(z["val"]).to(dev), torch.from_numpy(z["filled"]).to(dev), int(z["n_nodes"])), True
+        m = cls.compute(graph, seeds, coef, rmax, K)
+        tmp = path + f".tmp{os.getpid()}.npz"
+        np.savez(tmp, seeds=m.seeds, K=m.K, n_nodes=m.n_nodes, row=m.row.cpu().numpy(), col=m.col.cpu().numpy(),
+                 val=m.val.cpu().numpy(), filled=m.filled.cpu().numpy())
+        os.replace(tmp, path)
+        return m, False
+
+    # ---- hand-off ------------------------------------------------------------------------
+    def batch_positions(self, node_ids):
+        """int32 CUDA tensor of row positions for a batch of node ids (`topk_adj[batch_index]`, model.py:310).
+        Every id must be one of the seeds; for a duplicated seed the first position is used."""
+        import torch
+        if self._pos is None:
+            self._pos = {}
+            for i, s in enumerate(self.seeds.tolist()):
+                self._pos.setdefault(s, i)
+        try:
+            pos = np.fromiter((self._pos[int(v)] for v in np.asarray(node_ids).reshape(-1)), dtype=np.int32)
+        except KeyError as e:
+            raise KeyError(f"node {e.args[0]} is not among the seeds of this RowMatrix") from None
+        return torch.from_numpy(pos).to(self.col.device)
+
+    def to_scipy(self):
+        """`topk_adj` exactly as the reference builds it (model.py:270-272): a COO over ALL S*K slots -- unfilled
+        slots are (0, 0, 0.0) entries, as with the caller's zero-filled arrays -- converted to CSR."""
+        import scipy.sparse as sp
+        S = len(self.seeds)
+        f = self.filled.cpu().numpy()
+        m = (np.arange(self.K)[None, :] < f[:, None]).reshape(-1)
+        row = np.where(m, self.row.cpu().numpy(), 0); col = np.where(m, self.col.cpu().numpy(), 0)
+        val = np.where(m, self.val.cpu().numpy(), 0.0)
+        return sp.coo_matrix((val, (row, col)), (self.n_nodes, self.n_nodes)).tocsr()

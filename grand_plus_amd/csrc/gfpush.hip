@@ -41,8 +41,8 @@ int fail(int status, const char* fmt, ...) {
 struct Workspace {
     void* base = nullptr; size_t bytes = 0;
     int n_wg = 0;
-    u64 push_cap = 0, resg_cap = 0, log_cap = 0, cand_cap = 0;
-    PushEntry* push = nullptr; ResRec* resg = nullptr;
+    u64 push_cap = 0, resg_cap = 0, log_cap = 0, cand_cap = 0, bucket_cap = 0;
+    PushEntry* push = nullptr; ResRec* resg = nullptr; ResRec* bucket = nullptr;
     int* log_key = nullptr; double* log_val = nullptr; Cand* cand = nullptr;
     bool dirty = true;            // HBM residue tables need (re)initialising before the next launch
 };
@@ -121,14 +121,15 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
     const u64 log_cap = (u64)logn;
     const u64 cand_cap = (u64)supp + 1;
     const u64 push_cap = (u64)(f_max + e_max / kSplitLen + 2.0);
-    const size_t per_wg = 16 * (size_t)(2 * push_cap + resg_cap + cand_cap) + 12 * (size_t)log_cap + 64;
+    const u64 bucket_cap = (u64)e_max + 2;                 // (key, share) records of one bucketed level
+    const size_t per_wg = 16 * (size_t)(2 * push_cap + resg_cap + cand_cap + bucket_cap) + 12 * (size_t)log_cap + 64;
     const size_t budget = (size_t)g->workspace_mb << 20;
     int n_wg = n_wg_wanted;
     if ((size_t)n_wg * per_wg > budget) n_wg = (int)std::max<size_t>(1, budget / per_wg);
 
     Workspace& w = g->ws;
     const bool fits = w.base && w.n_wg >= n_wg && w.push_cap >= push_cap && w.resg_cap >= resg_cap &&
-                      w.log_cap >= log_cap && w.cand_cap >= cand_cap;
+                      w.log_cap >= log_cap && w.cand_cap >= cand_cap && w.bucket_cap >= bucket_cap;
     if (!fits) {
         free_workspace(w);
         const size_t total = (size_t)n_wg * per_wg + 4096;
@@ -138,11 +139,12 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
             return fail(GP_ERR_NOMEM, "hipMalloc(%zu bytes of gfpush workspace): %s", total, hipGetErrorString(e));
         }
         w.bytes = total; w.n_wg = n_wg;
-        w.push_cap = push_cap; w.resg_cap = resg_cap; w.log_cap = log_cap; w.cand_cap = cand_cap;
+        w.push_cap = push_cap; w.resg_cap = resg_cap; w.log_cap = log_cap; w.cand_cap = cand_cap; w.bucket_cap = bucket_cap;
         char* p = (char*)w.base;
         w.push = (PushEntry*)p; p += 16 * (size_t)n_wg * 2 * push_cap;
         w.resg = (ResRec*)p;    p += 16 * (size_t)n_wg * resg_cap;
         w.cand = (Cand*)p;      p += 16 * (size_t)n_wg * cand_cap;
+        w.bucket = (ResRec*)p;  p += 16 * (size_t)n_wg * bucket_cap;
         w.log_val = (double*)p; p += 8 * (size_t)n_wg * log_cap;
         w.log_key = (int*)p;
         w.dirty = true;
@@ -406,6 +408,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.resg = w.resg; kp.resg_cap = w.resg_cap;
     kp.log_key = w.log_key; kp.log_val = w.log_val; kp.log_cap = w.log_cap;
     kp.cand = w.cand; kp.cand_cap = w.cand_cap;
+    kp.bucket = w.bucket; kp.bucket_cap = w.bucket_cap;
     kp.counters = g->d_counters;
     kp.lds_slots = lds_slots;
     kp.force_global = g->force_global;

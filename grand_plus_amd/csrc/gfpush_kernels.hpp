@@ -53,9 +53,11 @@ constexpr int    kSplitLen   = 256;     // a long CSR range is split into chunks
 constexpr int    kLongLen    = 64;      // ranges longer than this are expanded by a whole wave
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
-constexpr int    kCtlBytes   = 256;     // control block at the start of dynamic LDS
+constexpr int    kCtlBytes   = 1280;    // control block at the start of dynamic LDS
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
+constexpr u32    kBucketMin  = 4;       // levels needing at least this many partitions bucket their edges in HBM once
+                                        // instead of re-reading and hash-filtering every CSR range once per partition
 constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many slots reports overflow
                                         // (recoverable: the level / aggregation is redone in more partitions)
 
@@ -79,6 +81,8 @@ struct LevelCtr {
 struct Ctl {
     long long row;        // row index pulled from the queue
     LevelCtr lc[2];       // what SCAN of level l produces for level l+1 lives in lc[l & 1]
+    u32 bcnt[64];         // bucketed levels: edges per bucket, then the scatter cursors
+    u32 boff[65];         // bucketed levels: first record of each bucket
     u32 log_count;        // reserve-log records so far
     u32 n_cand;           // top-K candidates (value > 0)
     u32 ovf;              // an LDS table partition overflowed (recoverable: more partitions)
@@ -132,6 +136,7 @@ struct KParams {
     ResRec* resg;    u64 resg_cap;       // per-workgroup HBM residue table
     int* log_key; double* log_val; u64 log_cap;   // per-workgroup reserve log
     Cand* cand;      u64 cand_cap;       // per-workgroup top-K candidates
+    ResRec* bucket;  u64 bucket_cap;     // per-workgroup (key, share) records of a bucketed level
     u64* counters;
     u32 lds_slots;
     int force_global;
@@ -489,6 +494,31 @@ __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lk
     if (n_long)  ok &= expand_list<BLOCK, IN_LDS, 2>(p, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts);
     if (n_short) ok &= expand_list<BLOCK, IN_LDS, 4>(p, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts);
     if (!ok) { if (IN_LDS) ctl->ovf = 1; else ctl->fail = 1; }
+}
+
+// ---------------------------------------------------------------- bucketed levels
+// A level that needs many LDS partitions (Amazon2M-shape at rmax 1e-6: ~100 k edges, ~14 partitions)
+// would re-read and hash-filter every CSR range once per partition.  Instead its edges are visited
+// three times in total: COUNT per bucket, SCATTER (key, share) records into per-bucket runs of an HBM
+// buffer, then one clean insert pass per bucket with every lane busy.
+template <int BLOCK, class F>
+__device__ __forceinline__ void for_each_edge(const KParams& p, const PushEntry* push, u32 n_short, u32 n_long, int log2g, F f)
+{
+    const int tid = threadIdx.x;
+    {   // long entries: a whole wave per entry
+        const int gl = tid & 63; const u32 gid = (u32)tid >> 6, n_groups = (u32)BLOCK >> 6;
+        for (u32 e = gid; e < n_long; e += n_groups) {
+            const PushEntry pe = push[(long long)p.push_cap - 1 - (long long)e];
+            for (int j = gl; j < pe.len; j += 64) f(p.indices[pe.start + j], pe.share);
+        }
+    }
+    {   // short entries: G lanes per entry
+        const int G = 1 << log2g, gl = tid & (G - 1); const u32 gid = (u32)tid >> log2g, n_groups = (u32)BLOCK >> log2g;
+        for (u32 e = gid; e < n_short; e += n_groups) {
+            const PushEntry pe = push[e];
+            for (int j = gl; j < pe.len; j += G) f(p.indices[pe.start + j], pe.share);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- TOP-K
@@ -945,7 +975,78 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             // Hash partitions (q, P) of the level's targets, refined in place on overflow exactly
             // like the aggregation partitions of topk_row (nothing to undo: a partition is
             // scanned only after its expansion succeeded).
-            if (!ctl->fail) {
+            const bool bucketed = in_lds && lvl > 0 && parts >= kBucketMin && parts <= 64 &&
+                                  (u64)e_cur + 1 <= p.bucket_cap;
+            if (!ctl->fail && bucketed) {
+                ResRec* bucket = p.bucket + wg * p.bucket_cap;
+                const u32 P = parts;
+                // COUNT
+                if (tid < 64) ctl->bcnt[tid] = 0;
+                __syncthreads();
+                GP_STAMP(t0);
+                for_each_edge<BLOCK>(p, push_cur, n_push_cur, n_long_cur, log2g, [&](int v, double) {
+                    __hip_atomic_fetch_add(&ctl->bcnt[slot_of(hash_b((u32)v), P)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                });
+                __syncthreads();
+                if (tid == 0) {
+                    u32 acc = 0;
+                    for (u32 b = 0; b < P; ++b) { ctl->boff[b] = acc; acc += ctl->bcnt[b]; ctl->bcnt[b] = ctl->boff[b]; }
+                    ctl->boff[P] = acc;
+                }
+                __syncthreads();
+                // SCATTER
+                for_each_edge<BLOCK>(p, push_cur, n_push_cur, n_long_cur, log2g, [&](int v, double share) {
+                    const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[slot_of(hash_b((u32)v), P)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ResRec r; r.key = v; r.pad = 0; r.val = share;
+                    bucket[i] = r;
+                });
+                __syncthreads();
+                GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
+                // one insert pass per bucket, refined in place (q of Q sub-partitions) if it still overflows
+                for (u32 b = 0; b < P && !ctl->fail; ++b) {
+                    const u32 lo = ctl->boff[b], hi = ctl->boff[b + 1];
+                    u32 q = 0, Q = 1;
+                    for (;;) {
+                        GP_STAMP(t0);
+                        const u32 want = b * Q + q, fine = P * Q;
+                        bool ok = true;
+                        for (u32 base = lo; base < hi; base += 4 * BLOCK) {
+                            ResRec rr[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const u32 i = base + (u32)u * BLOCK + tid;
+                                rr[u].key = kEmpty; rr[u].val = 0.0;
+                                if (i < hi) rr[u] = bucket[i];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (rr[u].key != kEmpty && (Q == 1 || slot_of(hash_b((u32)rr[u].key), fine) == want))
+                                    ok &= res_add_lds(lkeys, lvals, cap, rr[u].key, rr[u].val);          // graph.h:98
+                        }
+                        if (tid == 0 && has_dang_cur && slot_of(hash_b((u32)seed_key), fine) == want)       // graph.h:92
+                            ok &= res_add_lds(lkeys, lvals, cap, seed_key, dang_cur);
+                        if (!ok) ctl->ovf = 1;
+                        __syncthreads();
+                        GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
+                        if (ctl->ovf) {
+                            for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+                            __syncthreads();
+                            if (tid == 0) ctl->ovf = 0;
+                            if (Q < (1u << 20)) { q *= 2; Q *= 2; __syncthreads(); continue; }
+                            if (tid == 0) ctl->fail = 1;
+                            __syncthreads();
+                            break;
+                        }
+                        scan_level<BLOCK, true, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
+                        __syncthreads();
+                        GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2);
+                        if (ctl->fail) break;
+                        while (Q > 1 && (q & 1u)) { q >>= 1; Q >>= 1; }
+                        ++q;
+                        if (Q == 1) break;
+                    }
+                }
+            } else if (!ctl->fail) {
                 {
                     u32 part = 0, np = parts;
                     for (;;) {

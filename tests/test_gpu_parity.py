@@ -297,3 +297,33 @@ def test_dangling_nodes_with_packed_degrees():
     exp, ost = _oracle(indptr, indices, seeds, coef, 1e-6, 16)
     _assert_parity(seeds, 16, got, exp)
     assert ost["dangling"] > 0 and st["pushes"] == ost["pushes"]
+
+
+@pytest.mark.parametrize("shape,recipe,S,n_check", [("mag", ("mag", "ppr"), 4096, 64), ("amazon2m", ("amazon2m", "ppr"), 768, 24)])
+def test_full_scale_shapes(shape, recipe, S, n_check):
+    """BASELINE configs C5 / C4 at their full graph sizes (12.4 M / 173 M and 2.45 M / 61 M): properties that
+    need no oracle on every row, oracle parity on a sample.  Amazon2M-shape at rmax 1e-6 runs its big levels
+    through the bucketed-level path (~14 buckets)."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import RECIPES
+    indptr, indices = synth.shape_csr(shape)
+    n = len(indptr) - 1
+    seeds = synth.seeds(n, S)
+    r = RECIPES[recipe]
+    K = r.top_k
+    got, st = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, K)
+    row, col, val = (a.reshape(S, K) for a in got)
+    filled = (val > 0).sum(1)
+    assert st["failed_rows"] == 0 and st["global_levels"] == 0 and (filled >= 1).all()
+    mask = np.arange(K)[None, :] < filled[:, None]
+    assert (row[mask] == np.repeat(seeds, filled)).all()                      # row_idx == seed on filled slots
+    assert (np.diff(val, axis=1)[mask[:, 1:]] <= 0).all()                     # sorted by value
+    assert (val.sum(1) <= 1.0 + 1e-12).all()                                  # mass is never created
+    assert ((col[mask] >= 0) & (col[mask] < n)).all()
+    sub = np.linspace(0, S - 1, n_check).astype(int)
+    exp, ost = _oracle(indptr, indices, seeds[sub], r.coef(), r.rmax, K)
+    sel = tuple(a.reshape(S, K)[sub].reshape(-1) for a in got)
+    _assert_parity(seeds[sub], K, sel, exp)
+    # exact work counters on the sample agree with the oracle's
+    got2, st2 = _run_gpu(indptr, indices, seeds[sub], r.coef(), r.rmax, K, options={"exact_stats": 1})
+    assert (st2["pushes"], st2["edges"], st2["support"], st2["frontier"]) == (ost["pushes"], ost["edges"], ost["support_sum"], ost["frontier_sum"])

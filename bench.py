@@ -119,9 +119,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GRANDPLUS_BENCH_FORCE_DEVICE") is not None:      # debugging aid: several ranks on one GPU
+        local_rank = int(os.environ["GRANDPLUS_BENCH_FORCE_DEVICE"])
+    # RCCL ("nccl") is the product path.  GRANDPLUS_BENCH_BACKEND=gloo is a debugging aid for boxes with a
+    # single GPU (RCCL refuses two ranks on one device): same orchestration, the gather is staged through the host.
+    backend = os.environ.get("GRANDPLUS_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -162,7 +170,19 @@ def main():
         graph.gfpush_device(seeds_local, coef, recipe.rmax, K, row, col, val, filled)
 
     def step(i):
-        return gfpush_sharded(compute, shards[i], per, K, S_step, dev, packed=packed, gathered=gathered)
+        if backend == "nccl" or world == 1:
+            return gfpush_sharded(compute, shards[i], per, K, S_step, dev, packed=packed, gathered=gathered)
+        packed.filled.zero_()
+        compute(shards[i], packed.row, packed.col, packed.val, packed.filled)
+        gather_rows()
+
+    def gather_rows():
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, packed.buf[:packed.nbytes])
+        else:                                           # debugging aid only
+            host = torch.empty(world * packed.nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, packed.buf[:packed.nbytes].cpu())
+            gathered.copy_(host)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -183,11 +203,11 @@ def main():
         compute(shards[i], packed.row, packed.col, packed.val, packed.filled)
         ev[j][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, packed.buf[:packed.nbytes])
+            gather_rows()
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

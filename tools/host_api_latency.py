@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Latency of the drop-in entry point (host buffers in, host buffers out).
+
+Times `precompute.propagation.Graph.gfpush_omp` -- the pybind11 module a GRAND+ checkout imports
+(reference binding: precompute/propagation.cpp:8-12, call site model.py:268) -- on the committed
+Planetoid fixtures and on the MAG-shape synthetic graph, and prints the kernel time of the same
+call beside it.  The difference is the PCIe-inclusive overhead quoted in DESIGN.md section 4.
+Usage: python tools/host_api_latency.py [--calls 6]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: F401,E402  (one HIP runtime per process: torch first, see _native.lib)
+from grand_plus_amd import synth  # noqa: E402
+from grand_plus_amd import api  # noqa: E402
+from grand_plus_amd.recipes import RECIPES  # noqa: E402
+from precompute import propagation  # noqa: E402
+
+
+def time_calls(name, indptr, indices, seeds, coef, rmax, K, calls):
+    g = propagation.Graph(indptr, indices, 0)
+    S = len(seeds)
+    row = np.zeros(S * K, np.int32); col = np.zeros(S * K, np.int32); val = np.zeros(S * K)
+    ts = []
+    for _ in range(calls):
+        t = time.perf_counter()
+        g.gfpush_omp(seeds, row, col, val, coef, rmax, K)
+        ts.append((time.perf_counter() - t) * 1e3)
+    # kernel time of one identical call through the ctypes mirror (same library, same entry point)
+    g2 = api.Graph(indptr, indices, 0)
+    g2.gfpush_omp(seeds, row, col, val, coef, rmax, K)
+    g2.reset_stats()
+    g2.gfpush_omp(seeds, row, col, val, coef, rmax, K)
+    k_ms = g2.stats()["kernel_ms"]
+    steady = sorted(ts[1:])[len(ts[1:]) // 2]
+    print(json.dumps({"graph": name, "rows": S, "K": K, "first_call_ms": round(ts[0], 3),
+                      "median_call_ms": round(steady, 3), "max_call_ms": round(max(ts[1:]), 3),
+                      "kernel_ms": round(k_ms, 3), "rows_per_s_host_api": round(S / steady * 1e3)}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--calls", type=int, default=6)
+    a = ap.parse_args()
+    for name in ("cora", "citeseer", "pubmed"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        rmax, K = float(z["ppr_params"][0]), int(z["ppr_params"][1])
+        time_calls(name, z["indptr"], z["indices"], z["seeds"], z["ppr_coef"], rmax, K, a.calls)
+    r = RECIPES[("mag", "ppr")]
+    ip, ix = synth.shape_csr("mag")
+    for S in (16384, 65536):
+        time_calls("mag-shape", ip, ix, synth.seeds(len(ip) - 1, S), r.coef(), r.rmax, r.top_k, a.calls)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,8 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GRANDPLUS_DIAG=1 selects the diagnostic build (in-kernel phase stamps); never the default.
-LIB_PATH = os.path.join(_HERE, "libgrandplus_diag.so" if os.environ.get("GRANDPLUS_DIAG") == "1"
-                        else "libgrandplus.so")
+# GRANDPLUS_LIB=<file name in this directory> selects another HIP build of the same sources (A/B runs of
+# two kernel variants on the same GPU box, see tools/ab.sh); there is no non-HIP implementation to select.
+LIB_PATH = os.path.join(_HERE, os.environ.get("GRANDPLUS_LIB") or
+                        ("libgrandplus_diag.so" if os.environ.get("GRANDPLUS_DIAG") == "1" else "libgrandplus.so"))
 
 GP_OK = 0
 GP_ERR_NULL, GP_ERR_INVALID_CSR, GP_ERR_INVALID_SEED, GP_ERR_INVALID_ARG = 1, 2, 3, 4

@@ -362,7 +362,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         if (block_threads == 0) block_threads = 1024;
         if (lds_bytes == 0) lds_bytes = 160 * 1024;
     }
-    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~1u;     // even: keeps the key array 8-byte aligned
+    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~3u;     // multiple of 4: 128-bit LDS accesses on both arrays
     if ((size_t)lds_slots * 12 < kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap)
         return fail(GP_ERR_INVALID_ARG, "lds_bytes too small for K = %d", K);
 

@@ -427,6 +427,151 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr*
     }
 }
 
+// ---------------------------------------------------------------- SCAN, LDS tables: compact, then process
+// The table of a level is at most ~25-50 % full, and the per-node work (log record, push test,
+// degree lookup, push-list entry) is ~10x the work of looking at a slot.  Walking the table with
+// that code under an exec mask made SCAN VALU-issue bound at ~25 % lane use.  Here every wave
+// takes 256 consecutive slots per round: (a) each lane drains 4 adjacent slots with 128-bit LDS
+// accesses, (b) ballot/mbcnt positions compact the occupied (key, residue) pairs into the front
+// of the very slots just drained -- they are free, and LDS operations of one wave execute in
+// order -- and (c) the nodes are then processed 64 at a time with every lane busy.
+// Requires C % 4 == 0 and the invariant that slots in [cap, C) are empty.
+template <int BLOCK>
+__device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
+                                                 u32 cap, u32 C, int* log_key, double* log_val,
+                                                 PushEntry* push, double c, bool do_push,
+                                                 u64& st_push, u64& st_edges, u64& st_front, u64& st_deg)
+{
+    typedef int    i4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr u32 kRegion = 256;
+    u32 e_all = 0, e_sht = 0;                                       // edges of my pushes (all / short ranges)
+    for (u32 wb = (u32)(tid >> 6) * kRegion; wb < cap; wb += (u32)(BLOCK / 64) * kRegion) {
+        // (a) drain 4 adjacent slots per lane
+        const u32 s0 = wb + 4u * (u32)lane;
+        i4 kk = {kEmpty, kEmpty, kEmpty, kEmpty};
+        if (s0 < C) kk = *(const i4*)&lkeys[s0];
+        const bool o0 = kk.x != kEmpty, o1 = kk.y != kEmpty, o2 = kk.z != kEmpty, o3 = kk.w != kEmpty;
+        const u64 m0 = __ballot(o0), m1 = __ballot(o1), m2 = __ballot(o2), m3 = __ballot(o3);
+        const u32 c0 = (u32)__popcll(m0), c1 = (u32)__popcll(m1), c2 = (u32)__popcll(m2), c3 = (u32)__popcll(m3);
+        const u32 tot = c0 + c1 + c2 + c3;
+        if (tot == 0) continue;                                     // wave-uniform
+        if (o0 | o1 | o2 | o3) {
+            const d2 ra = *(const d2*)&lvals[s0], rb = *(const d2*)&lvals[s0 + 2];
+            const i4 ke = {kEmpty, kEmpty, kEmpty, kEmpty};
+            const d2 z = {0.0, 0.0};
+            *(i4*)&lkeys[s0] = ke; *(d2*)&lvals[s0] = z; *(d2*)&lvals[s0 + 2] = z;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);                // clears stay ahead of the staging stores
+            // (b) compact into [wb, wb + tot): item u of every lane precedes item u+1 of any lane
+            if (o0) { const u32 q = wb + lane_prefix(m0);                lkeys[q] = kk.x; lvals[q] = ra.x; }
+            if (o1) { const u32 q = wb + c0 + lane_prefix(m1);           lkeys[q] = kk.y; lvals[q] = ra.y; }
+            if (o2) { const u32 q = wb + c0 + c1 + lane_prefix(m2);      lkeys[q] = kk.z; lvals[q] = rb.x; }
+            if (o3) { const u32 q = wb + c0 + c1 + c2 + lane_prefix(m3); lkeys[q] = kk.w; lvals[q] = rb.y; }
+            st_front += (u32)o0 + (u32)o1 + (u32)o2 + (u32)o3;
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        u32 lb = 0;
+        if (lane == 0) lb = __hip_atomic_fetch_add(&ctl->log_count, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lb = (u32)__builtin_amdgcn_readfirstlane((int)lb);
+        // (c) dense processing: 2 x 64 nodes per step, so that the indptr loads of both halves are in flight together
+        constexpr int V = 2;
+        for (u32 j = 0; j < tot; j += 64 * V) {
+            int k[V]; double r[V]; bool act[V], want[V]; int ds[V], de[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const u32 idx = j + 64u * (u32)v + (u32)lane;
+                act[v] = idx < tot; k[v] = kEmpty; r[v] = 0.0; want[v] = false; ds[v] = 0; de[v] = 0;
+                if (act[v]) {
+                    k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
+                    lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
+                }
+            }
+            // degrees: the key carries min(deg, deg_sat) (see pack_degree_kernel); only nodes that DO push
+            // (they need their CSR offset) and saturated hubs read the two indptr words
+            if (do_push) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    if (act[v]) {
+                        const u32 dq = (u32)k[v] >> p.deg_shift;
+                        if (dq == 0u || r[v] >= p.rmax * (double)dq) {                    // graph.h:94
+                            const int node = (int)((u32)k[v] & p.node_mask);
+                            want[v] = true;
+                            ds[v] = p.indptr[node]; de[v] = p.indptr[node + 1]; ++st_deg;   // graph.h:43-45
+                        }
+                    }
+                }
+            }
+            // reserve log: one (node, coef*r) record per frontier node          graph.h:90 / :109
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                if (act[v]) {
+                    const u32 li = lb + j + 64u * (u32)v + (u32)lane;
+                    if (li < p.log_cap) { log_key[li] = k[v]; log_val[li] = c * r[v]; }
+                    else ctl->fail = 1;
+                }
+            }
+            if (!do_push) continue;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                if (__ballot(want[v]) == 0) continue;                                     // wave-uniform
+                bool is_short = false; u32 n_long = 0; double share = 0.0; int len = 0;
+                if (want[v]) {
+                    const u32 deg = (u32)(de[v] - ds[v]);
+                    if (deg == 0) {                                                       // graph.h:91-93
+                        __hip_atomic_fetch_add(&nx->dangling, r[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else if (r[v] >= p.rmax * (double)deg) {                            // graph.h:94
+                        ++st_push; st_edges += deg;
+                        const double sh = r[v] / (double)deg;                             // graph.h:95
+                        if (sh != 0.0) {
+                            share = sh; len = (int)deg;
+                            if (deg <= (u32)kLongLen) is_short = true;
+                            else n_long = (deg + kSplitLen - 1) / kSplitLen;
+                        }
+                    }
+                }
+                if (__ballot(len != 0) == 0) continue;                                    // wave-uniform: nobody pushes
+                // push lists: short ranges fill the buffer from the front, long-range chunks from the back
+                const u32 pi = wave_alloc1(&nx->n_push, is_short, lane);
+                u32 qi = 0;
+                if (__ballot(n_long != 0) != 0) qi = wave_alloc(&nx->n_long, n_long, lane);   // hubs only
+                if (len != 0) {
+                    e_all += (u32)len;
+                    if (is_short) {
+                        e_sht += (u32)len;
+                        // the two lists meet in the middle at worst: total entries <= push_cap by the host bound
+                        if ((u64)pi + nx->n_long < p.push_cap) {
+                            PushEntry pe; pe.start = ds[v]; pe.len = len; pe.share = share;
+                            push[pi] = pe;
+                        } else ctl->fail = 1;
+                    } else {
+                        for (int off = 0; off < len; off += kSplitLen) {
+                            if ((u64)qi + nx->n_push < p.push_cap) {
+                                PushEntry pe;
+                                pe.start = ds[v] + off;
+                                pe.len = min(kSplitLen, len - off);
+                                pe.share = share;
+                                push[p.push_cap - 1 - qi] = pe;
+                            } else ctl->fail = 1;
+                            ++qi;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // edge totals of the next level: one LDS atomic per wave (64 same-address atomics per step serialise)
+    if (do_push) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { e_all += __shfl_down(e_all, d); e_sht += __shfl_down(e_sht, d); }
+        if (lane == 0 && e_all) {
+            __hip_atomic_fetch_add(&nx->e_next, e_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (e_sht) __hip_atomic_fetch_add(&nx->e_short, e_sht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- EXPAND
 // Adds `share` into the next residue table for every column id of every push-list entry
 // (graph.h:96-99).  Long entries (chunks of hub ranges) take a whole wave each; short entries
@@ -1037,7 +1182,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             __syncthreads();
                             break;
                         }
-                        scan_level<BLOCK, true, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
+                        scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2);
                         if (ctl->fail) break;
@@ -1080,7 +1225,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             __syncthreads();
                             break;
                         }
-                        if (in_lds) scan_level<BLOCK, true,  4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
+                        if (in_lds) scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
                         else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);

@@ -1055,7 +1055,8 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
         if (tid == 0) {
             ctl->row = (long long)__hip_atomic_fetch_add(&p.counters[kQueue], 1ull, __ATOMIC_RELAXED,
                                                          __HIP_MEMORY_SCOPE_AGENT);
-            ctl->log_count = 0; ctl->n_cand = 0; ctl->fail = 0; ctl->ovf = 0;
+            ctl->log_count = 1;                         // record 0 is the seed's own (level 0, written below)
+            ctl->n_cand = 0; ctl->fail = 0; ctl->ovf = 0;
             ctl->n_sel = 0; ctl->n_bucket = 0;
         }
         __syncthreads();
@@ -1077,15 +1078,59 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
         bool has_dang_cur = false;
         int cur = 0;
 
-        for (int lvl = 0; lvl <= L; ++lvl) {
+        // ---- level 0 without a table: the frontier is { seed : 1.0 } (graph.h:81), so its reserve
+        //      record, its push test and its push-list entries are written directly.  This removes one
+        //      EXPAND/SCAN round trip (two barriers, a table walk and a dependent indptr load) per row.
+        {
+            const double c0 = p.coef[0];
+            const u32 s_start = (u32)p.indptr[seed];
+            PushEntry* push_nxt0 = push2 + (size_t)1 * p.push_cap;
+            if (tid == 0) {
+                if (p.log_cap > 0) { log_key[0] = seed_key; log_val[0] = c0; }                         // graph.h:90 / :109
+                else ctl->fail = 1;
+                ++st_front; ++st_deg;
+                if (p.force_global) ++st_glb; else ++st_lds;
+            }
+            n_levels = 1;
+            if (c0 > 0.0) { seg_begin = 0; seg_len = 1; }
+            if (L > 0) {
+                if (seed_deg == 0) {                                                  // graph.h:91-93
+                    dang_cur = 1.0; has_dang_cur = true;
+                } else if (1.0 >= p.rmax * (double)seed_deg) {                        // graph.h:94
+                    const double share = 1.0 / (double)seed_deg;                      // graph.h:95
+                    if (tid == 0) { ++st_push; st_edges += seed_deg; }
+                    if (share != 0.0) {
+                        e_cur = seed_deg;
+                        if (seed_deg <= (u32)kLongLen) {
+                            n_push_cur = 1; e_short_cur = seed_deg;
+                            if (tid == 0) {
+                                if (p.push_cap > 0) { PushEntry pe; pe.start = (int)s_start; pe.len = (int)seed_deg; pe.share = share; push_nxt0[0] = pe; }
+                                else ctl->fail = 1;
+                            }
+                        } else {
+                            n_long_cur = (seed_deg + kSplitLen - 1) / kSplitLen;
+                            if ((u64)n_long_cur > p.push_cap) { if (tid == 0) ctl->fail = 1; }
+                            else
+                                for (u32 q = (u32)tid; q < n_long_cur; q += BLOCK) {
+                                    PushEntry pe;
+                                    pe.start = (int)(s_start + q * (u32)kSplitLen);
+                                    pe.len = (int)min((u32)kSplitLen, seed_deg - q * (u32)kSplitLen);
+                                    pe.share = share;
+                                    push_nxt0[p.push_cap - 1 - q] = pe;
+                                }
+                        }
+                    }
+                }
+            }
+            cur = 1;
+            __syncthreads();                            // push entries / fail flag visible to every wave
+        }
+        for (int lvl = 1; lvl <= L; ++lvl) {
             const double c = p.coef[lvl];
             const bool do_push = lvl < L;                                     // graph.h:83 vs :104
             // distinct targets of this level <= min(edges (+ the seed), N)
-            u64 need = 1;
-            if (lvl > 0) {
-                need = min((u64)e_cur + (has_dang_cur ? 1 : 0), (u64)p.n_nodes);
-                if (need == 0) break;                   // the frontier died: later levels add nothing
-            }
+            const u64 need = min((u64)e_cur + (has_dang_cur ? 1 : 0), (u64)p.n_nodes);
+            if (need == 0) break;                       // the frontier died: later levels add nothing
             // placement of the level's residue table
             bool in_lds = !p.force_global;
             u32 parts = 1, cap = 0;
@@ -1120,7 +1165,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             // Hash partitions (q, P) of the level's targets, refined in place on overflow exactly
             // like the aggregation partitions of topk_row (nothing to undo: a partition is
             // scanned only after its expansion succeeded).
-            const bool bucketed = in_lds && lvl > 0 && parts >= kBucketMin && parts <= 64 &&
+            const bool bucketed = in_lds && parts >= kBucketMin && parts <= 64 &&
                                   (u64)e_cur + 1 <= p.bucket_cap;
             if (!ctl->fail && bucketed) {
                 ResRec* bucket = p.bucket + wg * p.bucket_cap;
@@ -1196,13 +1241,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     u32 part = 0, np = parts;
                     for (;;) {
                         GP_STAMP(t0);
-                        if (lvl == 0) {                                      // frontier { seed : 1.0 }   graph.h:81
-                            if (tid == 0) {
-                                const u32 s0 = slot_of(hash_a((u32)seed_key), cap);
-                                if (in_lds) { lkeys[s0] = seed_key; lvals[s0] = 1.0; }
-                                else { st_l2(&resg[s0].key, seed_key); st_l2(&resg[s0].val, 1.0); }
-                            }
-                        } else {
+                        {
                             if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
                             else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
                             if (tid == 0 && has_dang_cur &&

@@ -784,11 +784,18 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
         if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
         __syncthreads();
-        for (u32 i = tid; i < seg_len; i += BLOCK) {
-            const double v = log_val[seg_begin + i];
-            if (v > 0.0)
-                __hip_atomic_fetch_add(&hist[(u32)((u64)__double_as_longlong(v) >> 52)], 1u,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (u32 base = 0; base < seg_len; base += 8 * BLOCK) {              // 8 loads in flight per thread
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const u32 i = base + (u32)u * BLOCK + tid;
+                vv[u] = i < seg_len ? log_val[seg_begin + i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (vv[u] > 0.0)
+                    __hip_atomic_fetch_add(&hist[(u32)((u64)__double_as_longlong(vv[u]) >> 52)], 1u,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         if (wave == 0) topk_pick_bin(ctl, hist, K, lane);
@@ -802,31 +809,32 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             __syncthreads();
             GP_SUB(0);
             bool ok = true;
-            for (u32 base = 0; base < n_log && ok; base += 4 * BLOCK) {          // pass A: claim
-                int kk[4]; double vv[4];
+            constexpr int UA = 8;                                                 // records in flight per thread
+            for (u32 base = 0; base < n_log && ok; base += UA * BLOCK) {         // pass A: claim
+                int kk[UA]; double vv[UA];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UA; ++u) {
                     const u32 i = base + (u32)u * BLOCK + tid;
                     kk[u] = kEmpty; vv[u] = 0.0;
-                    if (i < n_log) { vv[u] = log_val[i]; if (vv[u] >= thr) kk[u] = log_key[i]; }   // keys of live records only
+                    if (i < n_log) { vv[u] = log_val[i]; kk[u] = log_key[i]; }   // both unconditionally: one latency, not two
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (kk[u] != kEmpty) ok &= lds_claim(akeys, CA, kk[u]);
+                for (int u = 0; u < UA; ++u)
+                    if (vv[u] >= thr) ok &= lds_claim(akeys, CA, kk[u]);
             }
             if (!ok) ctl->ovf = 1;
             __syncthreads();
             if (!ctl->ovf) {
-                for (u32 base = 0; base < n_log; base += 4 * BLOCK) {            // pass B: add
-                    int kk[4]; double vv[4];
+                for (u32 base = 0; base < n_log; base += UA * BLOCK) {           // pass B: add
+                    int kk[UA]; double vv[UA];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < UA; ++u) {
                         const u32 i = base + (u32)u * BLOCK + tid;
                         kk[u] = kEmpty; vv[u] = 0.0;
                         if (i < n_log) { kk[u] = log_key[i]; vv[u] = log_val[i]; }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < UA; ++u) {
                         if (kk[u] == kEmpty) continue;
                         const int slot = lds_find(akeys, CA, kk[u]);
                         if (slot >= 0)

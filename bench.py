@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--force-global", type=int, default=0)
+    ap.add_argument("--diag-flags", type=int, default=0, help="GRANDPLUS_DIAG=1 builds only: bit 0 skips TOP-K (instruction attribution)")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +154,8 @@ def main():
         graph.set_option("lds_bytes", args.lds_bytes)
     if args.force_global:
         graph.set_option("force_global", 1)
+    if args.diag_flags:
+        graph.set_option("diag_flags", args.diag_flags)
 
     per = args.seeds_per_gpu
     S_step = per * world

@@ -60,7 +60,7 @@ struct gp_graph {
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
-    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0;
+    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0;
     // per-call state
     Workspace ws;
     u64* d_counters = nullptr; u64* h_counters = nullptr;      // pinned host mirror
@@ -326,6 +326,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         g->force_global = value ? 1 : 0;
     } else if (k == "exact_stats") {
         g->exact_stats = value ? 1 : 0;
+    } else if (k == "diag_flags") {
+        g->diag_flags = (int)value;              // honoured by the -DGP_DIAG build only (bit 0: skip TOP-K)
     } else if (k == "max_degree_bits") {
         if (g->packed) return fail(GP_ERR_INVALID_ARG, "max_degree_bits must be set before the first gfpush call");
         if (value < 0 || value > 31) return fail(GP_ERR_INVALID_ARG, "max_degree_bits must be in [0, 31]");
@@ -417,6 +419,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.lds_slots = lds_slots;
     kp.force_global = g->force_global;
     kp.prune = g->exact_stats ? 0 : 1;
+    kp.diag_flags = g->diag_flags;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
 
     HIP_TRY(hipEventRecord(g->ev0, s));

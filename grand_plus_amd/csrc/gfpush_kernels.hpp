@@ -141,6 +141,7 @@ struct KParams {
     u32 lds_slots;
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
+    int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -445,73 +446,96 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
     typedef int    i4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63;
-    constexpr u32 kRegion = 256;
     u32 e_all = 0, e_sht = 0;                                       // edges of my pushes (all / short ranges)
-    for (u32 wb = (u32)(tid >> 6) * kRegion; wb < cap; wb += (u32)(BLOCK / 64) * kRegion) {
+    // Every wave owns ONE contiguous range of the table (a multiple of 256 slots) per level: it first
+    // compacts the whole range, then processes its nodes.  The steps of (c) each end in a wait for
+    // their indptr loads (and, vmcnt being shared, for the stores before them), so a level costs a
+    // wave ceil(nodes / (64 V)) such waits -- not one or two per 256 slots as when (a)-(c) alternated.
+    constexpr u32 kWaves = BLOCK / 64;
+    const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
+    const u32 wb = (u32)(tid >> 6) * range;
+    u32 tot = 0;
+    for (u32 sub = wb; sub < wb + range && sub < cap; sub += 256u) {
         // (a) drain 4 adjacent slots per lane
-        const u32 s0 = wb + 4u * (u32)lane;
+        const u32 s0 = sub + 4u * (u32)lane;
         i4 kk = {kEmpty, kEmpty, kEmpty, kEmpty};
         if (s0 < C) kk = *(const i4*)&lkeys[s0];
         const bool o0 = kk.x != kEmpty, o1 = kk.y != kEmpty, o2 = kk.z != kEmpty, o3 = kk.w != kEmpty;
         const u64 m0 = __ballot(o0), m1 = __ballot(o1), m2 = __ballot(o2), m3 = __ballot(o3);
         const u32 c0 = (u32)__popcll(m0), c1 = (u32)__popcll(m1), c2 = (u32)__popcll(m2), c3 = (u32)__popcll(m3);
-        const u32 tot = c0 + c1 + c2 + c3;
-        if (tot == 0) continue;                                     // wave-uniform
+        if (c0 + c1 + c2 + c3 == 0) continue;                       // wave-uniform
         if (o0 | o1 | o2 | o3) {
             const d2 ra = *(const d2*)&lvals[s0], rb = *(const d2*)&lvals[s0 + 2];
             const i4 ke = {kEmpty, kEmpty, kEmpty, kEmpty};
             const d2 z = {0.0, 0.0};
             *(i4*)&lkeys[s0] = ke; *(d2*)&lvals[s0] = z; *(d2*)&lvals[s0 + 2] = z;
             __atomic_signal_fence(__ATOMIC_SEQ_CST);                // clears stay ahead of the staging stores
-            // (b) compact into [wb, wb + tot): item u of every lane precedes item u+1 of any lane
-            if (o0) { const u32 q = wb + lane_prefix(m0);                lkeys[q] = kk.x; lvals[q] = ra.x; }
-            if (o1) { const u32 q = wb + c0 + lane_prefix(m1);           lkeys[q] = kk.y; lvals[q] = ra.y; }
-            if (o2) { const u32 q = wb + c0 + c1 + lane_prefix(m2);      lkeys[q] = kk.z; lvals[q] = rb.x; }
-            if (o3) { const u32 q = wb + c0 + c1 + c2 + lane_prefix(m3); lkeys[q] = kk.w; lvals[q] = rb.y; }
+            // (b) compact to the front of the range: [wb, wb + tot) lies inside the slots drained so far;
+            //     item u of every lane precedes item u+1 of any lane
+            const u32 q0 = wb + tot;
+            if (o0) { const u32 q = q0 + lane_prefix(m0);                lkeys[q] = kk.x; lvals[q] = ra.x; }
+            if (o1) { const u32 q = q0 + c0 + lane_prefix(m1);           lkeys[q] = kk.y; lvals[q] = ra.y; }
+            if (o2) { const u32 q = q0 + c0 + c1 + lane_prefix(m2);      lkeys[q] = kk.z; lvals[q] = rb.x; }
+            if (o3) { const u32 q = q0 + c0 + c1 + c2 + lane_prefix(m3); lkeys[q] = kk.w; lvals[q] = rb.y; }
             st_front += (u32)o0 + (u32)o1 + (u32)o2 + (u32)o3;
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        tot += c0 + c1 + c2 + c3;
+    }
+    if (tot != 0) {
         u32 lb = 0;
         if (lane == 0) lb = __hip_atomic_fetch_add(&ctl->log_count, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lb = (u32)__builtin_amdgcn_readfirstlane((int)lb);
-        // (c) dense processing: 2 x 64 nodes per step, so that the indptr loads of both halves are in flight together
-        constexpr int V = 2;
-        for (u32 j = 0; j < tot; j += 64 * V) {
-            int k[V]; double r[V]; bool act[V], want[V]; int ds[V], de[V];
+        // (c) every node: reserve record + the cheap part of the push test (the degree rides in the key).
+        //     Nodes that may push (~8 % on the power-law shapes) are compacted once more, to the front of
+        //     the slots consumed so far, so that the expensive part -- indptr lookup, fp64 division,
+        //     push-list allocation -- runs with full lanes in (d) instead of once per 64 nodes at ~5 lanes.
+        u32 ncand = 0;
+        constexpr int VC = 4;
+        for (u32 j = 0; j < tot; j += 64 * VC) {
+            int k[VC]; double r[VC]; bool cnd[VC];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
+            for (int v = 0; v < VC; ++v) {
                 const u32 idx = j + 64u * (u32)v + (u32)lane;
-                act[v] = idx < tot; k[v] = kEmpty; r[v] = 0.0; want[v] = false; ds[v] = 0; de[v] = 0;
-                if (act[v]) {
+                k[v] = kEmpty; r[v] = 0.0; cnd[v] = false;
+                if (idx < tot) {
                     k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
                     lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
-                }
-            }
-            // degrees: the key carries min(deg, deg_sat) (see pack_degree_kernel); only nodes that DO push
-            // (they need their CSR offset) and saturated hubs read the two indptr words
-            if (do_push) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    if (act[v]) {
-                        const u32 dq = (u32)k[v] >> p.deg_shift;
-                        if (dq == 0u || r[v] >= p.rmax * (double)dq) {                    // graph.h:94
-                            const int node = (int)((u32)k[v] & p.node_mask);
-                            want[v] = true;
-                            ds[v] = p.indptr[node]; de[v] = p.indptr[node + 1]; ++st_deg;   // graph.h:43-45
-                        }
-                    }
-                }
-            }
-            // reserve log: one (node, coef*r) record per frontier node          graph.h:90 / :109
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                if (act[v]) {
-                    const u32 li = lb + j + 64u * (u32)v + (u32)lane;
+                    // reserve log: one (node, coef*r) record per frontier node          graph.h:90 / :109
+                    const u32 li = lb + idx;
                     if (li < p.log_cap) { log_key[li] = k[v]; log_val[li] = c * r[v]; }
                     else ctl->fail = 1;
+                    // exact degree known and the test fails => dropped without touching memory   (graph.h:94);
+                    // a saturated field still says deg >= deg_sat, so r < rmax*deg_sat cannot push either
+                    const u32 dq = (u32)k[v] >> p.deg_shift;
+                    cnd[v] = do_push && (dq == 0u || r[v] >= p.rmax * (double)dq);
                 }
             }
             if (!do_push) continue;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);                // reads and clears stay ahead of the list stores
+#pragma unroll
+            for (int v = 0; v < VC; ++v) {
+                const u64 m = __ballot(cnd[v]);
+                if (cnd[v]) { const u32 q = wb + ncand + lane_prefix(m); lkeys[q] = k[v]; lvals[q] = r[v]; }
+                ncand += (u32)__popcll(m);                          // <= nodes consumed so far: stays inside cleared slots
+            }
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        // (d) the nodes that may push: V x 64 per step, their indptr loads in flight together
+        constexpr int V = 2;
+        for (u32 j = 0; j < ncand; j += 64 * V) {
+            int k[V]; double r[V]; bool want[V]; int ds[V], de[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const u32 idx = j + 64u * (u32)v + (u32)lane;
+                want[v] = idx < ncand; k[v] = kEmpty; r[v] = 0.0; ds[v] = 0; de[v] = 0;
+                if (want[v]) {
+                    k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
+                    lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
+                    const int node = (int)((u32)k[v] & p.node_mask);
+                    ds[v] = p.indptr[node]; de[v] = p.indptr[node + 1]; ++st_deg;           // graph.h:43-45
+                }
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 if (__ballot(want[v]) == 0) continue;                                     // wave-uniform
@@ -589,7 +613,7 @@ __device__ __forceinline__ bool res_add_any(int* lkeys, double* lvals, ResRec* r
 template <int BLOCK, bool IN_LDS, int B>
 __device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double* lvals, ResRec* resg, u32 cap,
                                             const PushEntry* list, long long stride_sign, u32 n_entries,
-                                            int log2g, u32 part, u32 parts)
+                                            int log2g, u32 part, u32 parts, bool dry = false)
 {
     const int tid = threadIdx.x;
     const int G = 1 << log2g;
@@ -604,6 +628,7 @@ __device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double
             const u32 e = e0 + (u32)b * n_groups;
             pe[b].start = 0; pe[b].len = 0; pe[b].share = 0.0;
             if (e < n_entries) pe[b] = list[stride_sign * (long long)e];
+            if (dry) pe[b].share = 0.0;          // GP_DIAG: a second, value-neutral pass (instruction attribution)
         }
         int v0[B], v1[B];
 #pragma unroll
@@ -633,11 +658,11 @@ __device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double
 template <int BLOCK, bool IN_LDS>
 __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
                                              ResRec* resg, u32 cap, const PushEntry* push,
-                                             u32 n_short, u32 n_long, int log2g, u32 part, u32 parts)
+                                             u32 n_short, u32 n_long, int log2g, u32 part, u32 parts, bool dry = false)
 {
     bool ok = true;
-    if (n_long)  ok &= expand_list<BLOCK, IN_LDS, 2>(p, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts);
-    if (n_short) ok &= expand_list<BLOCK, IN_LDS, 4>(p, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts);
+    if (n_long)  ok &= expand_list<BLOCK, IN_LDS, 2>(p, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts, dry);
+    if (n_short) ok &= expand_list<BLOCK, IN_LDS, 4>(p, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts, dry);
     if (!ok) { if (IN_LDS) ctl->ovf = 1; else ctl->fail = 1; }
 }
 
@@ -1252,6 +1277,9 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                         {
                             if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
                             else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
+#ifdef GP_DIAG
+                            if ((p.diag_flags & 2) && in_lds) expand_level<BLOCK, true>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np, true);
+#endif
                             if (tid == 0 && has_dang_cur &&
                                 (np == 1 || slot_of(hash_b((u32)seed_key), np) == part)) {          // graph.h:92
                                 const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed_key, dang_cur)
@@ -1304,6 +1332,9 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             continue;
         }
         GP_STAMP(t0);
+#ifdef GP_DIAG
+        if (!(p.diag_flags & 1))
+#endif
         topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, seg_begin, seg_len, n_levels, st_filled, st_support GP_SUB_ARGS);
         __syncthreads();
         if (ctl->fail && tid == 0) ++st_failed;

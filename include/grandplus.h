@@ -134,6 +134,8 @@ int gp_reset_stats(gp_graph* g);
  *   "exact_stats"     1 = always aggregate the whole reserve map, so that gp_stats.support is the
  *                      exact sum of reserve-map sizes (default 0: nodes that provably cannot
  *                      reach the top-K are never tabled and `support` counts only tabled nodes)
+ *   "diag_flags"      ignored by the product library; the diagnostic build (-DGP_DIAG) skips phases for
+ *                      instruction attribution (bit 0: TOP-K) -- its results are then meaningless
  * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.
  */
 int gp_set_option(gp_graph* g, const char* key, int64_t value);

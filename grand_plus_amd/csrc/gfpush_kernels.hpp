@@ -92,7 +92,20 @@ struct Ctl {
     u32 tk_bin;           // top-K: digit chosen this pass
     u32 tk_above;         // top-K: count strictly above the chosen digit this pass
     u32 tk_count;         // top-K: count inside the chosen digit
+    u64 st[12];           // statistics of this workgroup (Stat), flushed to p.counters once at the end
 };
+// Statistics live in LDS, not in registers: nine 64-bit per-thread counters alive for the whole kernel
+// cost 18 of the 128 VGPRs (spills).  Phases count in function-local registers and one lane per wave
+// adds the wave's totals here when the phase ends.
+enum Stat { sPush = 0, sEdges, sFront, sDeg, sFilled, sSupport, sLds, sGlb, sFailed, sNumStats };
+__device__ __forceinline__ void stat_add(Ctl* ctl, int which, u64 n) {
+    __hip_atomic_fetch_add(&ctl->st[which], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ u32 wave_sum32(u32 x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_down(x, d);
+    return x;                                   // valid in lane 0
+}
 
 enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
                kGlobalLevels, kFailedRows, kDegLookups,
@@ -308,10 +321,10 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
 template <int BLOCK, bool IN_LDS, int U>
 __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                            ResRec* resg, u32 cap, int* log_key, double* log_val,
-                                           PushEntry* push, double c, bool do_push,
-                                           u64& st_push, u64& st_edges, u64& st_front, u64& st_deg)
+                                           PushEntry* push, double c, bool do_push)
 {
     const int tid = threadIdx.x, lane = tid & 63;
+    u32 st_push = 0, st_edges = 0, st_front = 0, st_deg = 0;        // this thread, this level
     const u32 wave_first = (u32)(tid & ~63);
     for (u32 base = 0; base < cap; base += BLOCK * U) {
         if (base + wave_first >= cap) break;            // wave-uniform: nothing left for this wave
@@ -426,6 +439,12 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr*
             }
         }
     }
+    st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_front = wave_sum32(st_front); st_deg = wave_sum32(st_deg);
+    if (lane == 0) {
+        if (st_front) stat_add(ctl, sFront, st_front);
+        if (st_deg) stat_add(ctl, sDeg, st_deg);
+        if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
+    }
 }
 
 // ---------------------------------------------------------------- SCAN, LDS tables: compact, then process
@@ -440,13 +459,13 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr*
 template <int BLOCK>
 __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                                  u32 cap, u32 C, int* log_key, double* log_val,
-                                                 PushEntry* push, double c, bool do_push,
-                                                 u64& st_push, u64& st_edges, u64& st_front, u64& st_deg)
+                                                 PushEntry* push, double c, bool do_push)
 {
     typedef int    i4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63;
     u32 e_all = 0, e_sht = 0;                                       // edges of my pushes (all / short ranges)
+    u32 st_push = 0, st_edges = 0, st_deg = 0;                      // this thread, this level
     // Every wave owns ONE contiguous range of the table (a multiple of 256 slots) per level: it first
     // compacts the whole range, then processes its nodes.  The steps of (c) each end in a wait for
     // their indptr loads (and, vmcnt being shared, for the stores before them), so a level costs a
@@ -477,7 +496,6 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
             if (o1) { const u32 q = q0 + c0 + lane_prefix(m1);           lkeys[q] = kk.y; lvals[q] = ra.y; }
             if (o2) { const u32 q = q0 + c0 + c1 + lane_prefix(m2);      lkeys[q] = kk.z; lvals[q] = rb.x; }
             if (o3) { const u32 q = q0 + c0 + c1 + c2 + lane_prefix(m3); lkeys[q] = kk.w; lvals[q] = rb.y; }
-            st_front += (u32)o0 + (u32)o1 + (u32)o2 + (u32)o3;
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         tot += c0 + c1 + c2 + c3;
@@ -585,13 +603,22 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
             }
         }
     }
-    // edge totals of the next level: one LDS atomic per wave (64 same-address atomics per step serialise)
-    if (do_push) {
+    // edge totals of the next level and the statistics: one LDS atomic per wave (64 same-address
+    // atomics per step would serialise)
+    if (lane == 0 && tot) stat_add(ctl, sFront, tot);
+    if (do_push && tot) {
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { e_all += __shfl_down(e_all, d); e_sht += __shfl_down(e_sht, d); }
-        if (lane == 0 && e_all) {
-            __hip_atomic_fetch_add(&nx->e_next, e_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (e_sht) __hip_atomic_fetch_add(&nx->e_short, e_sht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int d = 32; d >= 1; d >>= 1) {
+            e_all += __shfl_down(e_all, d); e_sht += __shfl_down(e_sht, d);
+            st_push += __shfl_down(st_push, d); st_edges += __shfl_down(st_edges, d); st_deg += __shfl_down(st_deg, d);
+        }
+        if (lane == 0) {
+            if (e_all) {
+                __hip_atomic_fetch_add(&nx->e_next, e_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (e_sht) __hip_atomic_fetch_add(&nx->e_short, e_sht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (st_deg) stat_add(ctl, sDeg, st_deg);
+            if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
         }
     }
 }
@@ -758,7 +785,7 @@ template <int BLOCK>
 __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned char* scratch, u32 scratch_bytes,
                                          const int* log_key, const double* log_val, Cand* cand,
                                          long long row, int seed, u32 seg_begin, u32 seg_len, int n_levels,
-                                         u64& st_filled, u64& st_support GP_SUB_PARAMS)
+                                         int /*unused*/ GP_SUB_PARAMS)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32*  hist = (u32*)scratch;                                      // [kTopkBins]
@@ -775,7 +802,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     const u32 K = (u32)p.K;
 
     // turns the occupied slots of the aggregation table into candidates (+ first-digit histogram)
-    auto emit_candidates = [&](u64& n_nodes) {
+    auto emit_candidates = [&](u32& n_nodes) {
         for (u32 base = 0; base < CA; base += BLOCK) {
             const u32 slot = base + tid;
             bool keep = false;
@@ -804,7 +831,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     // record >= tau/n_levels, pass B adds ALL records of claimed nodes (read-only probe).  tau is
     // taken as the lower edge of the binade holding that K-th record (one histogram pass).
     bool pruned_done = false;
-    u64 live_nodes = 0;
+    u32 live_nodes = 0;
     if (p.prune && seg_len >= 4 * K && n_levels >= 1) {
         for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
         if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
@@ -881,7 +908,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         }
     }
     // ---- 1. full aggregation of the log -> candidates + first histogram
-    u64 support = 0;
+    u32 support = 0;
     if (!pruned_done) {
     // Key partitions are (p, P) = "keys whose hash falls in the p-th of P equal ranges".  A
     // partition that does not fit the table is split into (2p, 2P) and (2p+1, 2P) -- exactly
@@ -936,7 +963,10 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         }
     }
     }
-    st_support += pruned_done ? live_nodes : support;
+    {   // graph.h:111 res.size(): nodes this thread saw in the aggregation table(s)
+        const u32 n = wave_sum32(pruned_done ? live_nodes : support);
+        if (lane == 0 && n) stat_add(ctl, sSupport, n);
+    }
     const u32 m = ctl->n_cand;
     const u32 need = m < K ? m : K;                                   // graph.h:113
     if (need == 0 || ctl->fail) {
@@ -1044,7 +1074,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     }
     if (tid == 0) {
         if (p.out_filled) p.out_filled[row] = (int)need;
-        st_filled += need;
+        stat_add(ctl, sFilled, need);
     }
     GP_SUB(7);
 }
@@ -1071,8 +1101,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
     Cand* cand       = p.cand + wg * p.cand_cap;
 
     for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
-    u64 st_push = 0, st_edges = 0, st_front = 0, st_filled = 0, st_support = 0,
-        st_lds = 0, st_glb = 0, st_failed = 0, st_deg = 0;
+    if (tid < (int)(sizeof(ctl->st) / sizeof(ctl->st[0]))) ctl->st[tid] = 0;      // visible after the first row's barriers
     u64 tk_scan = 0, tk_expand = 0, tk_topk = 0, tk_total = 0, t0 = 0, t1 = 0, t2 = 0, tk_begin = 0;
     u64 tk_scan_hbm = 0, tk_expand_hbm = 0; (void)tk_scan_hbm; (void)tk_expand_hbm;
     (void)tk_scan; (void)tk_expand; (void)tk_topk; (void)tk_total; (void)t0; (void)t1; (void)t2; (void)tk_begin;
@@ -1097,7 +1126,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
         if (row >= p.n_seeds) break;
         const int seed = p.seeds[row];
         if (seed < 0 || seed >= p.n_nodes) {            // device API does not pre-validate seeds
-            if (tid == 0) { ++st_failed; if (p.out_filled) p.out_filled[row] = 0; }
+            if (tid == 0) { stat_add(ctl, sFailed, 1); if (p.out_filled) p.out_filled[row] = 0; }
             continue;
         }
 
@@ -1121,8 +1150,8 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             if (tid == 0) {
                 if (p.log_cap > 0) { log_key[0] = seed_key; log_val[0] = c0; }                         // graph.h:90 / :109
                 else ctl->fail = 1;
-                ++st_front; ++st_deg;
-                if (p.force_global) ++st_glb; else ++st_lds;
+                stat_add(ctl, sFront, 1); stat_add(ctl, sDeg, 1);
+                stat_add(ctl, p.force_global ? sGlb : sLds, 1);
             }
             n_levels = 1;
             if (c0 > 0.0) { seg_begin = 0; seg_len = 1; }
@@ -1131,7 +1160,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     dang_cur = 1.0; has_dang_cur = true;
                 } else if (1.0 >= p.rmax * (double)seed_deg) {                        // graph.h:94
                     const double share = 1.0 / (double)seed_deg;                      // graph.h:95
-                    if (tid == 0) { ++st_push; st_edges += seed_deg; }
+                    if (tid == 0) { stat_add(ctl, sPush, 1); stat_add(ctl, sEdges, seed_deg); }
                     if (share != 0.0) {
                         e_cur = seed_deg;
                         if (seed_deg <= (u32)kLongLen) {
@@ -1260,7 +1289,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             __syncthreads();
                             break;
                         }
-                        scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
+                        scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2);
                         if (ctl->fail) break;
@@ -1300,8 +1329,8 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             __syncthreads();
                             break;
                         }
-                        if (in_lds) scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
-                        else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push, st_push, st_edges, st_front, st_deg);
+                        if (in_lds) scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
+                        else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push);
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
                         if (ctl->fail) break;
@@ -1311,7 +1340,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     }
                 }
             }
-            if (tid == 0) { if (in_lds) ++st_lds; else ++st_glb; }
+            if (tid == 0) stat_add(ctl, in_lds ? sLds : sGlb, 1);
             {
                 const u32 lvl_len = ctl->log_count - snap_log;      // read after the level's last barrier
                 n_levels = lvl + 1;
@@ -1326,7 +1355,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
         if (ctl->fail) {
             // Leave the row unwritten and report it (GP_ERR_OVERFLOW).  Restore clean tables so
             // that later rows of this workgroup are unaffected.
-            if (tid == 0) { ++st_failed; if (p.out_filled) p.out_filled[row] = 0; }
+            if (tid == 0) { stat_add(ctl, sFailed, 1); if (p.out_filled) p.out_filled[row] = 0; }
             for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
             for (u64 i = tid; i < p.resg_cap; i += BLOCK) { st_l2(&resg[i].key, kEmpty); st_l2(&resg[i].val, 0.0); }
             continue;
@@ -1335,39 +1364,21 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
 #ifdef GP_DIAG
         if (!(p.diag_flags & 1))
 #endif
-        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, seg_begin, seg_len, n_levels, st_filled, st_support GP_SUB_ARGS);
+        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, seg_begin, seg_len, n_levels, 0 GP_SUB_ARGS);
         __syncthreads();
-        if (ctl->fail && tid == 0) ++st_failed;
+        if (ctl->fail && tid == 0) stat_add(ctl, sFailed, 1);
         GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);
         // top-K used the table region as scratch: restore the empty LDS table
         for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
     }
 
     // flush statistics: one atomic per counter per workgroup
-    st_push = wave_sum64(st_push); st_edges = wave_sum64(st_edges); st_front = wave_sum64(st_front);
-    st_support = wave_sum64(st_support); st_deg = wave_sum64(st_deg);
-    __syncthreads();
-    u64* red = (u64*)(smem + kCtlBytes);
-    if (tid < 8) red[tid] = 0;
-    __syncthreads();
-    if ((tid & 63) == 0) {
-        __hip_atomic_fetch_add(&red[0], st_push, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&red[1], st_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&red[2], st_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&red[3], st_support, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&red[4], st_deg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_fetch_add(&p.counters[kPushes], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kEdges], red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kFrontier], red[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kSupport], red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kDegLookups], red[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kFilled], st_filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kLdsLevels], st_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kGlobalLevels], st_glb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&p.counters[kFailedRows], st_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const Counter dst[sNumStats] = { kPushes, kEdges, kFrontier, kDegLookups, kFilled, kSupport, kLdsLevels, kGlobalLevels, kFailedRows };
+#pragma unroll
+        for (int i = 0; i < sNumStats; ++i)
+            if (ctl->st[i]) __hip_atomic_fetch_add(&p.counters[dst[i]], ctl->st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef GP_DIAG
         tk_total = wall_clock64() - tk_begin;
         __hip_atomic_fetch_add(&p.counters[kTicksScan], tk_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -352,34 +352,49 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     // a launch on a DIFFERENT stream first waits for the previous one
     if (g->launched && g->last_stream != s) HIP_TRY(hipStreamSynchronize(g->last_stream));
 
-    // Geometry.  Default: one 1024-thread workgroup per CU owning all 160 KB of LDS.  A graph so
-    // small that every level fits one table of HALF the LDS (N <= 0.75 * slots(80 KB)) runs two
-    // 512-thread workgroups per CU instead: their barriers and memory stalls overlap (Cora: +22 %).
-    int block_threads = g->block_threads, lds_bytes = g->lds_bytes;
-    if (block_threads == 0 && lds_bytes == 0) {
-        const bool tiny = (double)g->n_nodes <= 0.75 * (double)((80 * 1024 - kCtlBytes) / 12) && K <= 256;
-        block_threads = tiny ? 512 : 1024;
-        lds_bytes = tiny ? 80 * 1024 : 160 * 1024;
-    } else {
-        if (block_threads == 0) block_threads = 1024;
-        if (lds_bytes == 0) lds_bytes = 160 * 1024;
-    }
-    const u32 lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~3u;     // multiple of 4: 128-bit LDS accesses on both arrays
-    if ((size_t)lds_slots * 12 < kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap)
-        return fail(GP_ERR_INVALID_ARG, "lds_bytes too small for K = %d", K);
+    // Geometry.  Default: one 1024-thread workgroup per CU owning all 160 KB of LDS.  Two 512-thread
+    // workgroups per CU (80 KB each) overlap one row's barriers and memory stalls with another row's
+    // work; they win when the levels of a row are small next to the half-size table, and lose when a
+    // level then needs hash partitions.  Chosen automatically for (a) graphs so small that every level
+    // fits the half table (N <= 0.75 * slots(80 KB); Cora +16 %) and (b) sparse graphs, nnz < 8 N, whose
+    // frontiers stay small (Pubmed: +14 % ppr, +45 % avg, +90 % single; Citeseer +60 %).  Denser shapes
+    // keep 1 x 1024 (Reddit-shape loses 16 % with two workgroups, MAG-shape 1 %): tools/shape_sweep.py.
+    const bool auto_shape = g->block_threads == 0 && g->lds_bytes == 0;
+    const bool tiny = (double)g->n_nodes <= 0.75 * (double)((80 * 1024 - kCtlBytes) / 12);
+    const bool sparse = g->nnz < 8 * g->n_nodes;
+    bool two_per_cu = auto_shape && K <= 256 && (tiny || sparse);
+    int block_threads = 0, lds_bytes = 0, n_wg = 0;
+    u32 lds_slots = 0;
+    for (;;) {
+        block_threads = g->block_threads; lds_bytes = g->lds_bytes;
+        if (auto_shape) {
+            block_threads = two_per_cu ? 512 : 1024;
+            lds_bytes = two_per_cu ? 80 * 1024 : 160 * 1024;
+        } else {
+            if (block_threads == 0) block_threads = 1024;
+            if (lds_bytes == 0) lds_bytes = 160 * 1024;
+        }
+        lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~3u;     // multiple of 4: 128-bit LDS accesses on both arrays
+        if ((size_t)lds_slots * 12 < kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap)
+            return fail(GP_ERR_INVALID_ARG, "lds_bytes too small for K = %d", K);
 
-    int per_cu = 1;
-    switch (block_threads) {
-        case 256: rc = resident_blocks<256>(lds_bytes, &per_cu); break;
-        case 512: rc = resident_blocks<512>(lds_bytes, &per_cu); break;
-        default:  rc = resident_blocks<1024>(lds_bytes, &per_cu); break;
+        int per_cu = 1;
+        switch (block_threads) {
+            case 256: rc = resident_blocks<256>(lds_bytes, &per_cu); break;
+            case 512: rc = resident_blocks<512>(lds_bytes, &per_cu); break;
+            default:  rc = resident_blocks<1024>(lds_bytes, &per_cu); break;
+        }
+        if (rc) return rc;
+        n_wg = g->num_cus * per_cu;
+        if (g->max_workgroups > 0) n_wg = std::min(n_wg, g->max_workgroups);
+        n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(n_wg, n_seeds));
+        rc = ensure_workspace(g, n_coef, rmax, n_wg);
+        if (rc) return rc;
+        // the workspace budget could not hold two workgroups per CU: one big workgroup per CU is better than
+        // a half-empty chip
+        if (two_per_cu && g->ws.n_wg < n_wg && g->ws.n_wg < 2 * g->num_cus) { two_per_cu = false; continue; }
+        break;
     }
-    if (rc) return rc;
-    int n_wg = g->num_cus * per_cu;
-    if (g->max_workgroups > 0) n_wg = std::min(n_wg, g->max_workgroups);
-    n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(n_wg, n_seeds));
-    rc = ensure_workspace(g, n_coef, rmax, n_wg);
-    if (rc) return rc;
     rc = ensure_packed(g, s);
     if (rc) return rc;
     Workspace& w = g->ws;

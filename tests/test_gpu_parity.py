@@ -327,3 +327,55 @@ def test_full_scale_shapes(shape, recipe, S, n_check):
     # exact work counters on the sample agree with the oracle's
     got2, st2 = _run_gpu(indptr, indices, seeds[sub], r.coef(), r.rmax, K, options={"exact_stats": 1})
     assert (st2["pushes"], st2["edges"], st2["support"], st2["frontier"]) == (ost["pushes"], ost["edges"], ost["support_sum"], ost["frontier_sum"])
+
+
+def _random_digraph(rng, n, mean_deg, p_dangling, n_hubs, self_loops):
+    """Directed CSR with dangling nodes, a few hubs (out-degree ~ n/2) and optional self-loops."""
+    rows = []
+    hubs = set(rng.choice(n, size=min(n_hubs, n), replace=False).tolist())
+    for u in range(n):
+        if u in hubs:
+            deg = int(rng.integers(n // 3, max(n // 3 + 1, n // 2)))
+        elif rng.random() < p_dangling:
+            deg = 0
+        else:
+            deg = int(min(n - 1, 1 + rng.poisson(mean_deg)))
+        nb = rng.choice(n, size=deg, replace=False)
+        if self_loops and deg:
+            nb = np.unique(np.append(nb, u))
+        rows.append(np.sort(nb))
+    indptr = np.zeros(n + 1, np.int32); indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = (np.concatenate(rows) if indptr[-1] else np.zeros(0)).astype(np.int32)
+    return indptr, indices, sorted(hubs)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_digraphs_all_launch_shapes(case):
+    """Randomised differential test: random directed graphs (dangling nodes, hub seeds whose ranges are
+    chunked at level 0, duplicate seeds), random coefficient vectors (zeros included), rmax and K,
+    under the automatic launch shape and both forced ones, against the CPU oracle -- values, index sets
+    and the work counters."""
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.integers(40, 3000))
+    indptr, indices, hubs = _random_digraph(rng, n, mean_deg=float(rng.uniform(1.5, 12)),
+                                            p_dangling=float(rng.choice([0.0, 0.1, 0.4])),
+                                            n_hubs=int(rng.integers(0, 4)), self_loops=bool(case % 2))
+    L = int(rng.integers(1, 9))
+    coef = rng.random(L + 1)
+    coef[rng.random(L + 1) < 0.2] = 0.0
+    if coef.sum() == 0:
+        coef[-1] = 1.0
+    coef = coef / coef.sum()
+    rmax = float(10.0 ** rng.uniform(-7, -2))
+    K = int(rng.choice([1, 3, 16, 32, 100]))
+    seeds = rng.integers(0, n, size=300)
+    seeds[:len(hubs)] = hubs                      # hub seeds: level 0 writes chunked long entries
+    seeds[10:14] = seeds[10]                      # duplicate seeds give duplicate rows
+    exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
+    for opts in ({}, {"block_threads": 1024, "lds_bytes": 163840}, {"block_threads": 512, "lds_bytes": 81920},
+                 {"block_threads": 256, "lds_bytes": 40960}):
+        got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options=dict(opts, exact_stats=1))
+        _assert_parity(seeds, K, got, exp)
+        assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"], (opts, st, ost)
+        assert st["filled"] == ost["filled"] and st["frontier"] == ost["frontier_sum"]
+        assert st["support"] == ost["support_sum"] and st["failed_rows"] == 0

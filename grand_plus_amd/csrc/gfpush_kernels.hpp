@@ -1344,7 +1344,8 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             {
                 const u32 lvl_len = ctl->log_count - snap_log;      // read after the level's last barrier
                 n_levels = lvl + 1;
-                if (c > 0.0 && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
+                // first level with >= 4K records (early levels hold the LARGEST records: a stronger bound than the biggest level)
+                if (c > 0.0 && seg_len < 4u * (u32)p.K && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
             }
             if (ctl->fail || !do_push) break;
             n_push_cur = nx->n_push; n_long_cur = nx->n_long; e_cur = nx->e_next; e_short_cur = nx->e_short;

@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="mag", choices=sorted(WORKLOADS))
-    ap.add_argument("--seeds-per-gpu", type=int, default=16384)
+    ap.add_argument("--seeds-per-gpu", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--block-threads", type=int, default=0)

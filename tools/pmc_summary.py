@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Summarise the counter CSVs written by tools/collect_pmc.sh into one JSON (per-launch means of the
 timed gfpush_kernel launches: the first `--warmup` launches are dropped).
-Usage: python tools/pmc_summary.py <dir> <out.json> [--warmup 2] [--rows 16384]"""
+Usage: python tools/pmc_summary.py <dir> <out.json> [--warmup 2] [--rows 65536]"""
 import argparse, csv, glob, json, os
 from collections import defaultdict
 
 ap = argparse.ArgumentParser(); ap.add_argument("dir"); ap.add_argument("out")
-ap.add_argument("--warmup", type=int, default=2); ap.add_argument("--rows", type=int, default=16384)
+ap.add_argument("--warmup", type=int, default=2); ap.add_argument("--rows", type=int, default=65536)
 ap.add_argument("--workload", default="mag")
 a = ap.parse_args()
 per = {}

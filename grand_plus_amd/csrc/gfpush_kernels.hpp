@@ -92,6 +92,9 @@ struct Ctl {
     u32 tk_bin;           // top-K: digit chosen this pass
     u32 tk_above;         // top-K: count strictly above the chosen digit this pass
     u32 tk_count;         // top-K: count inside the chosen digit
+    u32 bovf;             // bucketed levels: a fixed-stride bucket overflowed (recoverable: the partition walk takes the level).
+                          // NB field offsets matter: shifting the fields above by 4 bytes cost 3 % (measured); this one
+                          // sits in what used to be alignment padding in front of st[]
     u64 st[12];           // statistics of this workgroup (Stat), flushed to p.counters once at the end
 };
 // Statistics live in LDS, not in registers: nine 64-bit per-thread counters alive for the whole kernel
@@ -1229,34 +1232,35 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             // scanned only after its expansion succeeded).
             const bool bucketed = in_lds && parts >= kBucketMin && parts <= 64 &&
                                   (u64)e_cur + 1 <= p.bucket_cap;
-            if (!ctl->fail && bucketed) {
-                ResRec* bucket = p.bucket + wg * p.bucket_cap;
-                const u32 P = parts;
-                // COUNT
+            bool use_buckets = !ctl->fail && bucketed;
+            ResRec* bucket = p.bucket + wg * p.bucket_cap;
+            const u32 P = parts;
+            if (use_buckets) {
+                // SCATTER into fixed-stride buckets: hash buckets of one level are nearly equal, and the
+                // buffer is sized for the worst level the bounds allow (E_max), typically ~10x this one, so
+                // a run of bucket_cap / P records per bucket almost never overflows and the edges are visited
+                // twice (scatter, insert) instead of three times (count, scatter, insert).  If a bucket does
+                // overflow (a hub collected a level's edges), the level takes the hash-partition walk below.
+                const u32 stride = (u32)min((u64)0xFFFFFFFFu, p.bucket_cap / P);
                 if (tid < 64) ctl->bcnt[tid] = 0;
+                if (tid == 0) ctl->bovf = 0;
                 __syncthreads();
                 GP_STAMP(t0);
-                for_each_edge<BLOCK>(p, push_cur, n_push_cur, n_long_cur, log2g, [&](int v, double) {
-                    __hip_atomic_fetch_add(&ctl->bcnt[slot_of(hash_b((u32)v), P)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                });
-                __syncthreads();
-                if (tid == 0) {
-                    u32 acc = 0;
-                    for (u32 b = 0; b < P; ++b) { ctl->boff[b] = acc; acc += ctl->bcnt[b]; ctl->bcnt[b] = ctl->boff[b]; }
-                    ctl->boff[P] = acc;
-                }
-                __syncthreads();
-                // SCATTER
                 for_each_edge<BLOCK>(p, push_cur, n_push_cur, n_long_cur, log2g, [&](int v, double share) {
-                    const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[slot_of(hash_b((u32)v), P)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ResRec r; r.key = v; r.pad = 0; r.val = share;
-                    bucket[i] = r;
+                    const u32 bk = slot_of(hash_b((u32)v), P);
+                    const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (i < stride) { ResRec r; r.key = v; r.pad = 0; r.val = share; bucket[(u64)bk * stride + i] = r; }
+                    else ctl->bovf = 1;
                 });
                 __syncthreads();
                 GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
+                if (ctl->bovf) use_buckets = false;
+                else { if (tid < 64 && (u32)tid < P) ctl->boff[tid] = (u32)tid * stride; __syncthreads(); }
+            }
+            if (use_buckets) {
                 // one insert pass per bucket, refined in place (q of Q sub-partitions) if it still overflows
                 for (u32 b = 0; b < P && !ctl->fail; ++b) {
-                    const u32 lo = ctl->boff[b], hi = ctl->boff[b + 1];
+                    const u32 lo = ctl->boff[b], hi = lo + ctl->bcnt[b];
                     u32 q = 0, Q = 1;
                     for (;;) {
                         GP_STAMP(t0);

@@ -379,3 +379,21 @@ def test_random_digraphs_all_launch_shapes(case):
         assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"], (opts, st, ost)
         assert st["filled"] == ost["filled"] and st["frontier"] == ost["frontier_sum"]
         assert st["support"] == ost["support_sum"] and st["failed_rows"] == 0
+
+
+def test_bucketed_level_bucket_overflow_falls_back_to_counting():
+    """rmax = 0 makes every level push every node, so a level's edges equal the workspace bound the
+    bucket buffer is sized from; with a tiny LDS budget those levels are bucketed, the fixed-stride
+    scatter overflows and the count -> prefix -> scatter path must take over without changing a row."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import make_coef
+    indptr, indices = synth.shape_csr("small")          # 100 k nodes, 1.48 M stored entries
+    seeds = synth.seeds(len(indptr) - 1, 24)
+    coef = make_coef("ppr", 4, 0.3)
+    K = 64
+    got, st = _run_gpu(indptr, indices, seeds, coef, 0.0, K,
+                       options={"block_threads": 256, "lds_bytes": 40960, "exact_stats": 1})
+    exp, ost = _oracle(indptr, indices, seeds, coef, 0.0, K)
+    _assert_parity(seeds, K, got, exp)
+    assert st["failed_rows"] == 0 and st["global_levels"] == 0
+    assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"] and st["support"] == ost["support_sum"]

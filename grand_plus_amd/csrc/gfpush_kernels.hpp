@@ -12,7 +12,11 @@
 //             deg==0        -> r returns to the seed             (graph.h:91-93)
 //             r >= rmax*deg -> append (CSR range, r/deg) to the next push list  (graph.h:94-95)
 //             else          -> r is dropped                      (no else branch)
-//           ballot + mbcnt prefix sums compact the log and the push lists.
+//           "Compact, then process" (scan_level_dense): every wave drains one contiguous range with
+//           128-bit LDS accesses, compacts the occupied (key, residue) pairs in place with ballot +
+//           mbcnt positions, handles the nodes with full lanes, and compacts the nodes that may push
+//           once more before the expensive part (indptr lookup, fp64 division, list allocation).
+//   LEVEL 0 is the seed alone: its record and push-list entries are written directly, no table.
 //   TOPK    sum the log per node in an LDS table (only nodes that can reach the top-K are
 //           tabled), radix-select the K largest (value desc, column asc) and write
 //           row/col/value at slot row*K+rank                      (graph.h:111-126).
@@ -22,7 +26,9 @@
 // distinct targets) exceeds 0.75 * slots is expanded in P hash PARTITIONS: pass p re-reads the
 // (L2-hot) CSR ranges and keeps only targets with part(v) == p, so the table never leaves LDS
 // and no global atomic is issued; a partition that still overflows is split in two in place.
-// Only levels needing more than kMaxParts passes use a per-workgroup table in HBM/L2.
+// From kBucketMin partitions on, the level's (target, share) pairs are scattered once into
+// fixed-stride hash buckets in HBM and inserted bucket by bucket instead.  Only levels needing
+// more than kMaxParts passes use a per-workgroup table in HBM/L2 (scan_level, the slot-walking SCAN).
 //
 // Table keys are the PACKED column ids of the device CSR: node id in the low bits and
 // min(deg(node), deg_sat) in the spare bits above it (pack_degree_kernel, once per graph).
@@ -318,9 +324,11 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
     return false;
 }
 
-// ---------------------------------------------------------------- SCAN
+// ---------------------------------------------------------------- SCAN (slot-walking form)
 // Drains the residue table of one level (or one partition of it).  U slots per thread are
 // handled per round so that the indptr loads of all U nodes are in flight together.
+// Since scan_level_dense took over the LDS tables this form is only instantiated for the HBM
+// table (IN_LDS = false): levels beyond kMaxParts partitions and the force_global test option.
 template <int BLOCK, bool IN_LDS, int U>
 __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                            ResRec* resg, u32 cap, int* log_key, double* log_val,

@@ -163,7 +163,7 @@ struct KParams {
     u32 lds_slots;
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
-    int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice
+    int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -1342,6 +1342,12 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             break;
                         }
                         if (in_lds) scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
+#ifdef GP_DIAG
+                        if ((p.diag_flags & 4) && in_lds) {          // a second walk over the (now empty) table: cost of stage (a) alone
+                            __syncthreads();
+                            scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
+                        }
+#endif
                         else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push);
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);

@@ -60,7 +60,7 @@ struct gp_graph {
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
-    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0;
+    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1;
     // per-call state
     Workspace ws;
     u64* d_counters = nullptr; u64* h_counters = nullptr;      // pinned host mirror
@@ -326,6 +326,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         g->force_global = value ? 1 : 0;
     } else if (k == "exact_stats") {
         g->exact_stats = value ? 1 : 0;
+    } else if (k == "direct_tables") {
+        g->direct_tables = value ? 1 : 0;        // 0 = always hash (testing / A-B of the direct-indexed small-graph tables)
     } else if (k == "diag_flags") {
         g->diag_flags = (int)value;              // honoured by the -DGP_DIAG build only (bit 0: skip TOP-K)
     } else if (k == "max_degree_bits") {
@@ -435,6 +437,8 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.force_global = g->force_global;
     kp.prune = g->exact_stats ? 0 : 1;
     kp.diag_flags = g->diag_flags;
+    // direct-indexed level tables: the whole graph fits the table of the 512-thread kernel (Cora, Citeseer)
+    kp.direct = (block_threads == 512 && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
 
     HIP_TRY(hipEventRecord(g->ev0, s));

@@ -163,6 +163,7 @@ struct KParams {
     u32 lds_slots;
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
+    int direct;                           // 1: every level's table is indexed by node id (N <= lds_slots; 512-thread kernel only)
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
 
@@ -273,6 +274,17 @@ __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, in
     }
     if (done) __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return done;
+}
+
+// Direct-indexed table for graphs with N <= slots (Cora, Citeseer): the slot IS the node id, so an insert
+// is one plain store of the packed key (every writer stores the same word) and one ds_add_f64 -- no
+// hash, no compare-and-swap, no probing loop -- and SCAN walks N slots instead of a 4x over-provisioned
+// hash table.
+__device__ __forceinline__ bool res_add_direct(int* keys, double* vals, u32 node_mask, int k, double v) {
+    const u32 slot = (u32)k & node_mask;
+    keys[slot] = k;
+    __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
 }
 
 // Claim a slot for k without touching its value (same probe sequence as res_add_lds).
@@ -643,12 +655,13 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
 // -- two exposed memory latencies per B entries instead of two per entry.
 // With parts > 1 only targets of hash partition `part` are kept (the others belong to a
 // later pass over the same list).
-template <bool IN_LDS>
-__device__ __forceinline__ bool res_add_any(int* lkeys, double* lvals, ResRec* resg, u32 cap, int v, double share) {
+template <bool IN_LDS, bool DIRECT>
+__device__ __forceinline__ bool res_add_any(int* lkeys, double* lvals, ResRec* resg, u32 cap, u32 node_mask, int v, double share) {
+    if (DIRECT) return res_add_direct(lkeys, lvals, node_mask, v, share);
     return IN_LDS ? res_add_lds(lkeys, lvals, cap, v, share) : res_add_hbm(resg, cap, v, share);
 }
 
-template <int BLOCK, bool IN_LDS, int B>
+template <int BLOCK, bool IN_LDS, int B, bool DIRECT>
 __device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double* lvals, ResRec* resg, u32 cap,
                                             const PushEntry* list, long long stride_sign, u32 n_entries,
                                             int log2g, u32 part, u32 parts, bool dry = false)
@@ -677,30 +690,30 @@ __device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             if (v0[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v0[b]), parts) == part))
-                ok &= res_add_any<IN_LDS>(lkeys, lvals, resg, cap, v0[b], pe[b].share);   // graph.h:98
+                ok &= res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v0[b], pe[b].share);   // graph.h:98
             if (v1[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v1[b]), parts) == part))
-                ok &= res_add_any<IN_LDS>(lkeys, lvals, resg, cap, v1[b], pe[b].share);
+                ok &= res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v1[b], pe[b].share);
         }
 #pragma unroll
         for (int b = 0; b < B; ++b) {                       // tails of entries longer than 2*G
             for (int j = gl + 2 * G; j < pe[b].len; j += G) {
                 const int v = p.indices[pe[b].start + j];
                 if (parts == 1 || slot_of(hash_b((u32)v), parts) == part)
-                    ok &= res_add_any<IN_LDS>(lkeys, lvals, resg, cap, v, pe[b].share);
+                    ok &= res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v, pe[b].share);
             }
         }
     }
     return ok;
 }
 
-template <int BLOCK, bool IN_LDS>
+template <int BLOCK, bool IN_LDS, bool DIRECT = false>
 __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
                                              ResRec* resg, u32 cap, const PushEntry* push,
                                              u32 n_short, u32 n_long, int log2g, u32 part, u32 parts, bool dry = false)
 {
     bool ok = true;
-    if (n_long)  ok &= expand_list<BLOCK, IN_LDS, 2>(p, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts, dry);
-    if (n_short) ok &= expand_list<BLOCK, IN_LDS, 4>(p, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts, dry);
+    if (n_long)  ok &= expand_list<BLOCK, IN_LDS, 2, DIRECT>(p, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts, dry);
+    if (n_short) ok &= expand_list<BLOCK, IN_LDS, 4, DIRECT>(p, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts, dry);
     if (!ok) { if (IN_LDS) ctl->ovf = 1; else ctl->fail = 1; }
 }
 
@@ -1207,7 +1220,11 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             // placement of the level's residue table
             bool in_lds = !p.force_global;
             u32 parts = 1, cap = 0;
-            if (in_lds) {
+            // direct-indexed tables (host sets p.direct only for the 512-thread kernel and N <= slots)
+            const bool direct = BLOCK == 512 && p.direct && in_lds;
+            if (direct) {
+                cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
+            } else if (in_lds) {
                 if (need * 4 <= (u64)C * 3) {
                     cap = (u32)min((u64)C, max((u64)kMinCap, 4 * need));
                 } else {
@@ -1316,6 +1333,10 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     for (;;) {
                         GP_STAMP(t0);
                         {
+                            if (BLOCK == 512 && direct) {
+                                expand_level<BLOCK, true, BLOCK == 512>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
+                                if (tid == 0 && has_dang_cur) res_add_direct(lkeys, lvals, p.node_mask, seed_key, dang_cur);       // graph.h:92
+                            } else {
                             if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
                             else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
 #ifdef GP_DIAG
@@ -1326,6 +1347,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                                 const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed_key, dang_cur)
                                                        : res_add_hbm(resg, cap, seed_key, dang_cur);
                                 if (!ok) { if (in_lds) ctl->ovf = 1; else ctl->fail = 1; }
+                            }
                             }
                         }
                         __syncthreads();

@@ -134,6 +134,8 @@ int gp_reset_stats(gp_graph* g);
  *   "exact_stats"     1 = always aggregate the whole reserve map, so that gp_stats.support is the
  *                      exact sum of reserve-map sizes (default 0: nodes that provably cannot
  *                      reach the top-K are never tabled and `support` counts only tabled nodes)
+ *   "direct_tables"   0 = never index the level tables by node id (default 1: graphs with N <= table slots of the
+ *                      512-thread kernel -- Cora, Citeseer -- skip hashing altogether)
  *   "diag_flags"      ignored by the product library; the diagnostic build (-DGP_DIAG) skips phases for
  *                      instruction attribution (bit 0: TOP-K) -- its results are then meaningless
  * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.

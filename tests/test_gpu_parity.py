@@ -372,8 +372,9 @@ def test_random_digraphs_all_launch_shapes(case):
     seeds[:len(hubs)] = hubs                      # hub seeds: level 0 writes chunked long entries
     seeds[10:14] = seeds[10]                      # duplicate seeds give duplicate rows
     exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
+    # default shape (direct-indexed tables when the graph fits), both forced shapes, the hashed 512-thread form
     for opts in ({}, {"block_threads": 1024, "lds_bytes": 163840}, {"block_threads": 512, "lds_bytes": 81920},
-                 {"block_threads": 256, "lds_bytes": 40960}):
+                 {"block_threads": 512, "lds_bytes": 81920, "direct_tables": 0}, {"block_threads": 256, "lds_bytes": 40960}):
         got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options=dict(opts, exact_stats=1))
         _assert_parity(seeds, K, got, exp)
         assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"], (opts, st, ost)

@@ -262,18 +262,21 @@ __device__ __forceinline__ void wave_alloc_flags(u32* lds_counter, const bool (&
 // Keys never revert to EMPTY while inserts are running, so a key ends up in exactly one slot.
 __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {
     u32 slot = slot_of(hash_a((u32)k), cap);
-    bool done = false;
+    // A lane leaves the loop as soon as its compare-and-swap hit; `step` is wave-uniform, so the
+    // give-up test is scalar, and failure is encoded in `slot` instead of a second flag.
 #pragma unroll 1
-    for (u32 step = 1; step <= kMaxProbe; ++step) {
+    for (u32 step = 1;; ++step) {
         int seen = kEmpty;
         __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (seen == kEmpty || seen == k) { done = true; break; }
+        if (seen == kEmpty || seen == k) break;
+        if (step == kMaxProbe) { slot = 0xFFFFFFFFu; break; }
         slot += step;
         if (slot >= cap) slot -= cap;
     }
-    if (done) __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return done;
+    if (slot == 0xFFFFFFFFu) return false;
+    __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
 }
 
 // Direct-indexed table for graphs with N <= slots (Cora, Citeseer): the slot IS the node id, so an insert

@@ -279,6 +279,24 @@ __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, in
     return true;
 }
 
+// Same insert, reporting failure through a sticky LDS flag instead of a return value: the callers that
+// insert eight keys per step would otherwise fold eight results into a lane mask (4 SALU each).
+__device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 cap, int k, double v, u32* flag) {
+    u32 slot = slot_of(hash_a((u32)k), cap);
+#pragma unroll 1
+    for (u32 step = 1;; ++step) {
+        int seen = kEmpty;
+        __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen == kEmpty || seen == k) break;
+        if (step == kMaxProbe) { slot = 0xFFFFFFFFu; break; }
+        slot += step;
+        if (slot >= cap) slot -= cap;
+    }
+    if (slot == 0xFFFFFFFFu) *flag = 1u;
+    else __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Direct-indexed table for graphs with N <= slots (Cora, Citeseer): the slot IS the node id, so an insert
 // is one plain store of the packed key (every writer stores the same word) and one ds_add_f64 -- no
 // hash, no compare-and-swap, no probing loop -- and SCAN walks N slots instead of a 4x over-provisioned
@@ -659,13 +677,14 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
 // With parts > 1 only targets of hash partition `part` are kept (the others belong to a
 // later pass over the same list).
 template <bool IN_LDS, bool DIRECT>
-__device__ __forceinline__ bool res_add_any(int* lkeys, double* lvals, ResRec* resg, u32 cap, u32 node_mask, int v, double share) {
-    if (DIRECT) return res_add_direct(lkeys, lvals, node_mask, v, share);
-    return IN_LDS ? res_add_lds(lkeys, lvals, cap, v, share) : res_add_hbm(resg, cap, v, share);
+__device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* resg, u32 cap, u32 node_mask, int v, double share, u32* flag) {
+    if (DIRECT) { res_add_direct(lkeys, lvals, node_mask, v, share); return; }
+    if (IN_LDS) res_add_lds_flag(lkeys, lvals, cap, v, share, flag);
+    else if (!res_add_hbm(resg, cap, v, share)) *flag = 1u;
 }
 
 template <int BLOCK, bool IN_LDS, int B, bool DIRECT>
-__device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double* lvals, ResRec* resg, u32 cap,
+__device__ __forceinline__ void expand_list(const KParams& p, u32* flag, int* lkeys, double* lvals, ResRec* resg, u32 cap,
                                             const PushEntry* list, long long stride_sign, u32 n_entries,
                                             int log2g, u32 part, u32 parts, bool dry = false)
 {
@@ -674,7 +693,6 @@ __device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double
     const int gl = tid & (G - 1);
     const u32 gid = (u32)tid >> log2g;
     const u32 n_groups = (u32)BLOCK >> log2g;
-    bool ok = true;
     for (u32 e0 = gid; e0 < n_entries; e0 += n_groups * B) {
         PushEntry pe[B];
 #pragma unroll
@@ -693,20 +711,19 @@ __device__ __forceinline__ bool expand_list(const KParams& p, int* lkeys, double
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             if (v0[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v0[b]), parts) == part))
-                ok &= res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v0[b], pe[b].share);   // graph.h:98
+                res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v0[b], pe[b].share, flag);   // graph.h:98
             if (v1[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v1[b]), parts) == part))
-                ok &= res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v1[b], pe[b].share);
+                res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v1[b], pe[b].share, flag);
         }
 #pragma unroll
         for (int b = 0; b < B; ++b) {                       // tails of entries longer than 2*G
             for (int j = gl + 2 * G; j < pe[b].len; j += G) {
                 const int v = p.indices[pe[b].start + j];
                 if (parts == 1 || slot_of(hash_b((u32)v), parts) == part)
-                    ok &= res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v, pe[b].share);
+                    res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v, pe[b].share, flag);
             }
         }
     }
-    return ok;
 }
 
 template <int BLOCK, bool IN_LDS, bool DIRECT = false>
@@ -714,10 +731,9 @@ __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lk
                                              ResRec* resg, u32 cap, const PushEntry* push,
                                              u32 n_short, u32 n_long, int log2g, u32 part, u32 parts, bool dry = false)
 {
-    bool ok = true;
-    if (n_long)  ok &= expand_list<BLOCK, IN_LDS, 2, DIRECT>(p, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts, dry);
-    if (n_short) ok &= expand_list<BLOCK, IN_LDS, 4, DIRECT>(p, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts, dry);
-    if (!ok) { if (IN_LDS) ctl->ovf = 1; else ctl->fail = 1; }
+    u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
+    if (n_long)  expand_list<BLOCK, IN_LDS, 2, DIRECT>(p, flag, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts, dry);
+    if (n_short) expand_list<BLOCK, IN_LDS, 4, DIRECT>(p, flag, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts, dry);
 }
 
 // ---------------------------------------------------------------- bucketed levels

@@ -398,3 +398,20 @@ def test_bucketed_level_bucket_overflow_falls_back_to_counting():
     _assert_parity(seeds, K, got, exp)
     assert st["failed_rows"] == 0 and st["global_levels"] == 0
     assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"] and st["support"] == ost["support_sum"]
+
+
+def test_hub_seeds_level0_chunked_entries():
+    """Seeds with the largest degrees of the power-law shape: level 0 writes their range as many
+    256-column chunks (all threads), and their first levels are the widest of the graph."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import make_coef
+    indptr, indices = synth.shape_csr("small")
+    deg = np.diff(indptr)
+    seeds = np.argsort(deg)[-12:].astype(np.int64)
+    assert deg[seeds].max() > 2000
+    coef = make_coef("ppr", 4, 0.2)
+    for rmax in (1e-5, 1e-7):                       # 1e-5: hubs above 1/rmax edges do not push at all
+        got, st = _run_gpu(indptr, indices, seeds, coef, rmax, 32, options={"exact_stats": 1})
+        exp, ost = _oracle(indptr, indices, seeds, coef, rmax, 32)
+        _assert_parity(seeds, 32, got, exp)
+        assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"] and st["failed_rows"] == 0

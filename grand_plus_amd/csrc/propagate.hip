@@ -54,13 +54,19 @@ spmm_kernel(const int* __restrict__ indptr, const int* __restrict__ indices, con
             double acc[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
-            int j = begin;
-            for (; j + 8 <= end; j += 8) {
+            // 8 neighbour rows in flight per lane, the ragged tail included: a slot past the end re-reads the
+            // row's last neighbour (cache hit) with weight 0 -- a serial tail loop would expose one full HBM
+            // latency per remaining neighbour, and most rows of these graphs are shorter than 16.  (Keeping
+            // the full batches unpredicated and predicating only the last one was measured 5 % slower on the
+            // MAG and Amazon2M shapes, 3 % faster on the Reddit shape.)
+            for (int j = begin; j < end; j += 8) {
                 V v[8]; float w[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const u32 c = (u32)indices[j + u] & node_mask;
-                    w[u] = wts ? wts[j + u] : 1.0f;
+                    const bool live = j + u < end;
+                    const int jj = live ? j + u : end - 1;
+                    const u32 c = (u32)indices[jj] & node_mask;
+                    w[u] = live ? (wts ? wts[jj] : 1.0f) : 0.0f;
                     v[u] = *reinterpret_cast<const V*>(x + (size_t)c * F + f);
                 }
 #pragma unroll
@@ -69,14 +75,6 @@ spmm_kernel(const int* __restrict__ indptr, const int* __restrict__ indices, con
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] += (double)w[u] * (double)pv[i];       // adj.dot(features), model.py:191
                 }
-            }
-            for (; j < end; ++j) {
-                const u32 c = (u32)indices[j] & node_mask;
-                const float w = wts ? wts[j] : 1.0f;
-                const V v = *reinterpret_cast<const V*>(x + (size_t)c * F + f);
-                const float* pv = reinterpret_cast<const float*>(&v);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] += (double)w * (double)pv[i];
             }
             V y; float* py = reinterpret_cast<float*>(&y);
 #pragma unroll

@@ -553,7 +553,7 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
         //     the slots consumed so far, so that the expensive part -- indptr lookup, fp64 division,
         //     push-list allocation -- runs with full lanes in (d) instead of once per 64 nodes at ~5 lanes.
         u32 ncand = 0;
-        constexpr int VC = 4;
+        constexpr int VC = 2;
         for (u32 j = 0; j < tot; j += 64 * VC) {
             int k[VC]; double r[VC]; bool cnd[VC];
 #pragma unroll

@@ -437,6 +437,9 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.force_global = g->force_global;
     kp.prune = g->exact_stats ? 0 : 1;
     kp.diag_flags = g->diag_flags;
+    // short/long split of the push list: sparse shapes (mean degree <= 24: MAG-like, citation graphs) do better with
+    // 32 (+1.8 % on the MAG shape), denser ones with 64 (the Reddit shape loses 2 % at 32); tools/ab.sh sweep
+    kp.long_len = (g->nnz <= 24 * g->n_nodes) ? 32u : (u32)kLongLen;
     // direct-indexed level tables: the whole graph fits the table of the 512-thread kernel (Cora, Citeseer)
     kp.direct = (block_threads == 512 && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0

@@ -56,7 +56,7 @@ typedef unsigned int u32;
 
 constexpr int    kEmpty      = -1;
 constexpr int    kSplitLen   = 256;     // a long CSR range is split into chunks of this many columns
-constexpr int    kLongLen    = 64;      // ranges longer than this are expanded by a whole wave
+constexpr int    kLongLen    = 64;      // upper limit of KParams::long_len (ranges longer than long_len are expanded by a whole wave)
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
 constexpr int    kCtlBytes   = 1280;    // control block at the start of dynamic LDS
@@ -76,7 +76,7 @@ struct Cand      { u64 bits;  int key; int pad;  };      // 16 B  top-K candidat
 struct LevelCtr {
     double dangling;      // mass returned to the seed by dangling nodes
     u32 n_dangling;       // how many dangling nodes were drained
-    u32 n_push;           // SHORT push-list entries (range length <= kLongLen), growing from the front
+    u32 n_push;           // SHORT push-list entries (range length <= long_len), growing from the front
     u32 n_long;           // LONG entries (chunks of <= kSplitLen), growing from the back of the same buffer
     u32 e_short;          // edges covered by the short entries
     u32 e_next;           // all edges the next EXPAND will traverse
@@ -163,6 +163,7 @@ struct KParams {
     u32 lds_slots;
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
+    u32 long_len;                         // CSR ranges up to this length are 'short' (G lanes per range), longer ones take a wave
     int direct;                           // 1: every level's table is indexed by node id (N <= lds_slots; 512-thread kernel only)
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
@@ -443,7 +444,7 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr*
                     if (sh != 0.0) {
                         share[u] = sh; len[u] = (int)deg;
                         e_sum += deg;
-                        if (deg <= (u32)kLongLen) { is_short[u] = true; e_short += deg; }
+                        if (deg <= p.long_len) { is_short[u] = true; e_short += deg; }
                         else n_long += (deg + kSplitLen - 1) / kSplitLen;
                     }
                 }
@@ -612,7 +613,7 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
                         const double sh = r[v] / (double)deg;                             // graph.h:95
                         if (sh != 0.0) {
                             share = sh; len = (int)deg;
-                            if (deg <= (u32)kLongLen) is_short = true;
+                            if (deg <= p.long_len) is_short = true;
                             else n_long = (deg + kSplitLen - 1) / kSplitLen;
                         }
                     }
@@ -1206,7 +1207,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     if (tid == 0) { stat_add(ctl, sPush, 1); stat_add(ctl, sEdges, seed_deg); }
                     if (share != 0.0) {
                         e_cur = seed_deg;
-                        if (seed_deg <= (u32)kLongLen) {
+                        if (seed_deg <= p.long_len) {
                             n_push_cur = 1; e_short_cur = seed_deg;
                             if (tid == 0) {
                                 if (p.push_cap > 0) { PushEntry pe; pe.start = (int)s_start; pe.len = (int)seed_deg; pe.share = share; push_nxt0[0] = pe; }

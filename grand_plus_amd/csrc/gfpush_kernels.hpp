@@ -55,7 +55,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int    kEmpty      = -1;
-constexpr int    kSplitLen   = 256;     // a long CSR range is split into chunks of this many columns
+constexpr int    kSplitLen   = 128;     // a long CSR range is split into chunks of this many columns
 constexpr int    kLongLen    = 64;      // upper limit of KParams::long_len (ranges longer than long_len are expanded by a whole wave)
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
@@ -876,7 +876,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     // taken as the lower edge of the binade holding that K-th record (one histogram pass).
     bool pruned_done = false;
     u32 live_nodes = 0;
-    if (p.prune && seg_len >= 4 * K && n_levels >= 1) {
+    if (p.prune && seg_len >= 2 * K && n_levels >= 1) {
         for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
         if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
         __syncthreads();
@@ -1404,8 +1404,8 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             {
                 const u32 lvl_len = ctl->log_count - snap_log;      // read after the level's last barrier
                 n_levels = lvl + 1;
-                // first level with >= 4K records (early levels hold the LARGEST records: a stronger bound than the biggest level)
-                if (c > 0.0 && seg_len < 4u * (u32)p.K && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
+                // first level with >= 2K records (early levels hold the LARGEST records: a stronger bound than the biggest level)
+                if (c > 0.0 && seg_len < 2u * (u32)p.K && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
             }
             if (ctl->fail || !do_push) break;
             n_push_cur = nx->n_push; n_long_cur = nx->n_long; e_cur = nx->e_next; e_short_cur = nx->e_short;

@@ -65,6 +65,7 @@ constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts w
 constexpr u32    kBucketMin  = 4;       // levels needing at least this many partitions bucket their edges in HBM once
                                         // instead of re-reading and hash-filtering every CSR range once per partition
 constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many slots reports overflow
+constexpr u32    kProbeSpan  = kMaxProbe * (kMaxProbe + 1) / 2;   // furthest a triangular probe sequence can walk (300 slots)
                                         // (recoverable: the level / aggregation is redone in more partitions)
 
 struct PushEntry { int start; int len; double share; };  // 16 B
@@ -179,6 +180,11 @@ __device__ __forceinline__ u32 hash_b(u32 k) {            // partition choice (i
     return k;
 }
 __device__ __forceinline__ u32 slot_of(u32 h, u32 cap) { return (u32)(((u64)h * cap) >> 32); }
+// Home slot in an LDS table of `cap` slots.  Homes lie in [0, cap - kProbeSpan): a probe sequence then
+// never leaves [0, cap), so the probing loops need no wrap-around (4 VALU per probe); 2 % of a full
+// table is the price.  Every LDS table has cap >= kMinCap > kProbeSpan.
+static_assert(kMinCap > 2 * kProbeSpan, "every LDS table must be much larger than the probe span");
+__device__ __forceinline__ u32 home_lds(u32 k, u32 cap) { return slot_of(hash_a(k), cap - kProbeSpan); }
 
 // L2-coherent (L1-bypassing) accesses for tables that are also touched by atomics.
 template <class T> __device__ __forceinline__ T ld_l2(const T* p) {
@@ -262,7 +268,7 @@ __device__ __forceinline__ void wave_alloc_flags(u32* lds_counter, const bool (&
 // a handful of instructions, which matters because this path is instruction-issue bound.
 // Keys never revert to EMPTY while inserts are running, so a key ends up in exactly one slot.
 __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {
-    u32 slot = slot_of(hash_a((u32)k), cap);
+    u32 slot = home_lds((u32)k, cap);
     // A lane leaves the loop as soon as its compare-and-swap hit; `step` is wave-uniform, so the
     // give-up test is scalar, and failure is encoded in `slot` instead of a second flag.
 #pragma unroll 1
@@ -272,8 +278,7 @@ __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, in
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (seen == kEmpty || seen == k) break;
         if (step == kMaxProbe) { slot = 0xFFFFFFFFu; break; }
-        slot += step;
-        if (slot >= cap) slot -= cap;
+        slot += step;                               // stays below cap, see home_lds
     }
     if (slot == 0xFFFFFFFFu) return false;
     __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -283,7 +288,7 @@ __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, in
 // Same insert, reporting failure through a sticky LDS flag instead of a return value: the callers that
 // insert eight keys per step would otherwise fold eight results into a lane mask (4 SALU each).
 __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 cap, int k, double v, u32* flag) {
-    u32 slot = slot_of(hash_a((u32)k), cap);
+    u32 slot = home_lds((u32)k, cap);
 #pragma unroll 1
     for (u32 step = 1;; ++step) {
         int seen = kEmpty;
@@ -291,8 +296,7 @@ __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 ca
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (seen == kEmpty || seen == k) break;
         if (step == kMaxProbe) { slot = 0xFFFFFFFFu; break; }
-        slot += step;
-        if (slot >= cap) slot -= cap;
+        slot += step;                               // stays below cap, see home_lds
     }
     if (slot == 0xFFFFFFFFu) *flag = 1u;
     else __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -311,28 +315,26 @@ __device__ __forceinline__ bool res_add_direct(int* keys, double* vals, u32 node
 
 // Claim a slot for k without touching its value (same probe sequence as res_add_lds).
 __device__ __forceinline__ bool lds_claim(int* keys, u32 cap, int k) {
-    u32 slot = slot_of(hash_a((u32)k), cap);
+    u32 slot = home_lds((u32)k, cap);
 #pragma unroll 1
     for (u32 step = 1; step <= kMaxProbe; ++step) {
         int seen = kEmpty;
         __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (seen == kEmpty || seen == k) return true;
-        slot += step;
-        if (slot >= cap) slot -= cap;
+        slot += step;                               // stays below cap, see home_lds
     }
     return false;
 }
 // Read-only lookup (no inserts may run concurrently): slot of k, or -1.
 __device__ __forceinline__ int lds_find(const int* keys, u32 cap, int k) {
-    u32 slot = slot_of(hash_a((u32)k), cap);
+    u32 slot = home_lds((u32)k, cap);
 #pragma unroll 1
     for (u32 step = 1; step <= kMaxProbe; ++step) {
         const int seen = keys[slot];
         if (seen == k) return (int)slot;
         if (seen == kEmpty) return -1;
-        slot += step;
-        if (slot >= cap) slot -= cap;
+        slot += step;                               // stays below cap, see home_lds
     }
     return -1;
 }

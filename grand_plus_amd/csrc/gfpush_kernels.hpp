@@ -1385,14 +1385,17 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             __syncthreads();
                             break;
                         }
-                        if (in_lds) scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
-#ifdef GP_DIAG
-                        if ((p.diag_flags & 4) && in_lds) {          // a second walk over the (now empty) table: cost of stage (a) alone
-                            __syncthreads();
+                        if (in_lds) {
                             scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
-                        }
+#ifdef GP_DIAG
+                            if (p.diag_flags & 4) {                  // a second walk over the (now empty) table: cost of stage (a) alone
+                                __syncthreads();
+                                scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
+                            }
 #endif
-                        else        scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push);
+                        } else {
+                            scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push);
+                        }
                         __syncthreads();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
                         if (ctl->fail) break;

@@ -879,7 +879,11 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     bool pruned_done = false;
     u32 live_nodes = 0;
     if (p.prune && seg_len >= 2 * K && n_levels >= 1) {
-        for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+        // Binade histogram of the segment in the 64 words of ctl->bcnt (free outside bucketed levels):
+        // records are <= 1, so bin b = 1023 - biased exponent counts [2^-b, 2^-b+1); bin 63 also takes
+        // everything smaller and then gives no threshold.  (A 4096-bin sign+exponent histogram in the
+        // scratch LDS did the same at the price of clearing and scanning 4096 words per row.)
+        if (tid < 64) ctl->bcnt[tid] = 0;
         if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
         __syncthreads();
         for (u32 base = 0; base < seg_len; base += 8 * BLOCK) {              // 8 loads in flight per thread
@@ -891,15 +895,22 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (vv[u] > 0.0)
-                    __hip_atomic_fetch_add(&hist[(u32)((u64)__double_as_longlong(vv[u]) >> 52)], 1u,
+                if (vv[u] > 0.0) {
+                    const int e = 1023 - (int)((u64)__double_as_longlong(vv[u]) >> 52);
+                    __hip_atomic_fetch_add(&ctl->bcnt[(u32)min(max(e, 0), 63)], 1u,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
         }
         __syncthreads();
-        if (wave == 0) topk_pick_bin(ctl, hist, K, lane);
+        if (wave == 0) {
+            const u32 incl = wave_incl_scan(ctl->bcnt[lane], lane);          // records >= 2^-lane
+            const u64 m = __ballot(incl >= K);
+            if (lane == 0) ctl->tk_bin = m ? (u32)__ffsll((long long)m) - 1u : 0xFFFFFFFFu;
+        }
         __syncthreads();
-        const u32 bin = ctl->tk_bin;
+        const u32 binade = ctl->tk_bin;
         __syncthreads();
+        const u32 bin = binade >= 63u ? 0u : 1023u - binade;                 // biased exponent of tau; 0 = no threshold
         if (bin != 0xFFFFFFFFu && bin != 0) {
             const double tau = __longlong_as_double((long long)((u64)bin << 52));
             const double thr = tau / (double)n_levels * 0.99999;

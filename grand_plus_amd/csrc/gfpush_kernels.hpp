@@ -103,6 +103,7 @@ struct Ctl {
                           // NB field offsets matter: shifting the fields above by 4 bytes cost 3 % (measured); this one
                           // sits in what used to be alignment padding in front of st[]
     u64 st[12];           // statistics of this workgroup (Stat), flushed to p.counters once at the end
+    u32 tk_wide;          // top-K: a candidate lies outside [2^-63, 2): the first digit needs the 4096-bin histogram
 };
 // Statistics live in LDS, not in registers: nine 64-bit per-thread counters alive for the whole kernel
 // cost 18 of the 128 VGPRs (spills).  Phases count in function-local registers and one lane per wave
@@ -864,7 +865,12 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             const u32 ci = wave_alloc1(&ctl->n_cand, keep, lane);
             if (keep) {
                 if (ci < p.cand_cap) cand[ci] = c; else ctl->fail = 1;
-                __hip_atomic_fetch_add(&hist[(u32)(c.bits >> 52)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // first radix digit = sign+exponent; candidates are > 0 and practically all in [2^-63, 2), so the
+                // digit histogram is 64 binade counters in ctl->bcnt (see the threshold pass); anything else
+                // raises tk_wide and the select re-counts the first digit in the 4096-bin histogram
+                const int e = 1023 - (int)(c.bits >> 52);
+                if ((u32)e < 64u) __hip_atomic_fetch_add(&ctl->bcnt[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else ctl->tk_wide = 1u;
             }
         }
     };
@@ -950,7 +956,8 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                             __hip_atomic_fetch_add(&avals[slot], vv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+                if (tid < 64) ctl->bcnt[tid] = 0;                        // binade counters of the first digit (emit_candidates)
+                if (tid == 0) ctl->tk_wide = 0;
                 __syncthreads();
                 GP_SUB(1);
                 emit_candidates(live_nodes);
@@ -974,7 +981,8 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     u32 P0 = 1;
     // distinct nodes are typically ~0.6 of the records: aim at ~0.7 load
     if ((u64)n_log * 10 > (u64)CA * 6) P0 = (u32)(((u64)n_log * 6 + (u64)CA * 5 - 1) / ((u64)CA * 5));
-    for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
+    if (tid < 64) ctl->bcnt[tid] = 0;                        // binade counters of the first digit (emit_candidates)
+    if (tid == 0) ctl->tk_wide = 0;
     if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
     // Depth-first walk over the partition tree with two registers and no stack: (part, parts)
     // is split into (2*part, 2*parts) on overflow; after a completed RIGHT child (odd part) the
@@ -1044,7 +1052,8 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         int depth = 0;              // digits fixed so far
         bool take_all = false;
         for (;;) {
-            if (depth > 0) {
+            const bool binades = depth == 0 && !ctl->tk_wide;          // first digit counted in 64 binade counters
+            if (!binades) {
                 for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
                 __syncthreads();
                 for (u32 i = tid; i < cur_n; i += BLOCK) {
@@ -1056,7 +1065,15 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                 __syncthreads();
             }
             GP_SUB(3); GP_SUB_COUNT(compacted ? 10 : 9, 1);
-            if (wave == 0) topk_pick_bin(ctl, hist, want, lane);
+            if (wave == 0) {
+                if (binades) {                                           // lane = binade: values in [2^-lane, 2^-lane+1)
+                    const u32 c = ctl->bcnt[lane];
+                    const u32 incl = wave_incl_scan(c, lane);            // candidates >= 2^-lane
+                    const u64 mk = __ballot(incl >= want);               // never empty: want <= K < m candidates
+                    const int bl = mk ? __ffsll((long long)mk) - 1 : 63;
+                    if (lane == bl) { ctl->tk_bin = 1023u - (u32)bl; ctl->tk_above = incl - c; ctl->tk_count = c; }
+                } else topk_pick_bin(ctl, hist, want, lane);
+            }
             __syncthreads();
             GP_SUB(4);
             prefix = pre_push(prefix, depth, ctl->tk_bin);

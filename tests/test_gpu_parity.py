@@ -415,3 +415,19 @@ def test_hub_seeds_level0_chunked_entries():
         exp, ost = _oracle(indptr, indices, seeds, coef, rmax, 32)
         _assert_parity(seeds, 32, got, exp)
         assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"] and st["failed_rows"] == 0
+
+
+@pytest.mark.parametrize("scale", [1e-25, 8.0, 1.0])
+def test_candidate_values_outside_the_binade_counters(scale):
+    """Top-K counts the first radix digit in 64 binade counters covering [2^-63, 2); coefficient vectors that
+    put the reserve values below or above that range (the API does not require normalised coefficients)
+    must take the 4096-bin path and give the same rows."""
+    from grand_plus_amd import synth
+    indptr, indices = synth.shape_csr("tiny")
+    seeds = synth.seeds(len(indptr) - 1, 96)
+    coef = np.array([0.5, 0.25, 0.125, 0.0625]) * scale
+    for K in (4, 64):
+        got, st = _run_gpu(indptr, indices, seeds, coef, 1e-6, K)
+        exp, _ = _oracle(indptr, indices, seeds, coef, 1e-6, K)
+        _assert_parity(seeds, K, got, exp)
+        assert st["failed_rows"] == 0

@@ -26,7 +26,7 @@ EXPORTS = (
     "gp_graph_create", "gp_graph_destroy", "gp_graph_num_nodes", "gp_graph_nnz",
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
-    "gp_propagate_features", "gp_internal_graph_csr",
+    "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
 )
 
 
@@ -109,6 +109,8 @@ def lib():
                                      ctypes.c_float, ctypes.c_int, ctypes.c_uint64, vp, vp, vp]
     L.gp_propagate_features.restype = ctypes.c_int
     L.gp_propagate_features.argtypes = [vp, vp, ctypes.c_int32, vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, vp]
+    L.gp_internal_diag_counters.restype = ctypes.c_int
+    L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     if L.gp_abi_version() != 1:

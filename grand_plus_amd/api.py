@@ -168,6 +168,12 @@ class Graph:
         _native.raise_for_status(rc)
         return st.as_dict()
 
+    def diag_counters(self):
+        """Extended counters of the diagnostic build (GRANDPLUS_DIAG=1); zeros in the product library."""
+        buf = (ctypes.c_int64 * 128)()
+        _native.raise_for_status(_native.lib().gp_internal_diag_counters(self._h, buf, 128))
+        return list(buf)
+
     def set_option(self, key: str, value: int):
         _native.raise_for_status(_native.lib().gp_set_option(self._h, key.encode(), int(value)))
 

@@ -217,6 +217,13 @@ int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indic
     return GP_OK;
 }
 
+int gp_internal_diag_counters(gp_graph* g, int64_t* out, int n) {
+    if (!g || !out) return fail(GP_ERR_NULL, "null argument");
+    if (g->launched) { HIP_TRY(hipSetDevice(g->device)); HIP_TRY(hipStreamSynchronize(g->last_stream)); }
+    for (int i = 0; i < n; ++i) out[i] = i < 128 && g->launched ? (int64_t)g->h_counters[kDiagX0 + i] : 0;
+    return GP_OK;
+}
+
 void gp_internal_set_error(int status, const char* where, const char* detail) {
     (void)fail(status, "%s: %s", where ? where : "", detail ? detail : "");
 }
@@ -311,7 +318,7 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     if (!g || !key) return fail(GP_ERR_NULL, "null argument");
     const std::string k(key);
     if (k == "block_threads") {
-        if (value != 256 && value != 512 && value != 1024) return fail(GP_ERR_INVALID_ARG, "block_threads must be 256, 512 or 1024");
+        if (value != 256 && value != 512 && value != 768 && value != 1024) return fail(GP_ERR_INVALID_ARG, "block_threads must be 256, 512, 768 or 1024");
         g->block_threads = (int)value;
     } else if (k == "lds_bytes") {
         if (value < 40 * 1024 || value > 160 * 1024) return fail(GP_ERR_INVALID_ARG, "lds_bytes must be in [40960, 163840]");
@@ -377,13 +384,18 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
             if (lds_bytes == 0) lds_bytes = 160 * 1024;
         }
         lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~3u;     // multiple of 4: 128-bit LDS accesses on both arrays
-        if ((size_t)lds_slots * 12 < kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap)
-            return fail(GP_ERR_INVALID_ARG, "lds_bytes too small for K = %d", K);
+        // TOP-K carves hist[4096] | sel[K] | tie[kBucketCap] out of the table region and aggregates in what is
+        // left; like every LDS table that aggregation table needs >= kMinCap slots (home_lds: cap - kProbeSpan)
+        const size_t topk_fixed = kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap;
+        if ((size_t)lds_slots * 12 < topk_fixed + 12 * (size_t)kMinCap)
+            return fail(GP_ERR_INVALID_ARG, "lds_bytes = %d too small for K = %d (top-K needs %zu bytes of LDS)",
+                        lds_bytes, K, topk_fixed + 12 * (size_t)kMinCap + kCtlBytes);
 
         int per_cu = 1;
         switch (block_threads) {
             case 256: rc = resident_blocks<256>(lds_bytes, &per_cu); break;
             case 512: rc = resident_blocks<512>(lds_bytes, &per_cu); break;
+            case 768: rc = resident_blocks<768>(lds_bytes, &per_cu); break;
             default:  rc = resident_blocks<1024>(lds_bytes, &per_cu); break;
         }
         if (rc) return rc;
@@ -449,6 +461,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         switch (block_threads) {
             case 256: rc = launch_kernel<256>(kp, n_wg, lds_bytes, s); break;
             case 512: rc = launch_kernel<512>(kp, n_wg, lds_bytes, s); break;
+            case 768: rc = launch_kernel<768>(kp, n_wg, lds_bytes, s); break;
             default:  rc = launch_kernel<1024>(kp, n_wg, lds_bytes, s); break;
         }
         if (rc) return rc;

@@ -104,6 +104,10 @@ struct Ctl {
                           // sits in what used to be alignment padding in front of st[]
     u64 st[12];           // statistics of this workgroup (Stat), flushed to p.counters once at the end
     u32 tk_wide;          // top-K: a candidate lies outside [2^-63, 2): the first digit needs the 4096-bin histogram
+#ifdef GP_DIAG
+    u64 barw[16];         // per wave: shader cycles spent waiting at workgroup barriers
+    u32 barn[16];         // per wave: barriers passed
+#endif
 };
 // Statistics live in LDS, not in registers: nine 64-bit per-thread counters alive for the whole kernel
 // cost 18 of the 128 VGPRs (spills).  Phases count in function-local registers and one lane per wave
@@ -122,10 +126,18 @@ enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLe
                kGlobalLevels, kFailedRows, kDegLookups,
                kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
                kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
+               kDiagX0, kDiagXLast = kDiagX0 + 127,   // GP_DIAG: [0] wave cycles, [1] cycles waves spent at barriers, [2] barriers; [16 + 6*lvl + k] per level:
+                                                    //   k = 0 expand ticks, 1 scan ticks, 2 edges, 3 frontier nodes, 4 push entries, 5 table passes
                kNumCounters };
 
 // Phase stamps exist only in the diagnostic build (-DGP_DIAG): thread 0 reads the constant
 // 100 MHz clock at phase boundaries.  The product build compiles them to nothing.
+// Workgroup barrier.  The diagnostic build measures what the waves spend waiting at it (shader cycles).
+#ifdef GP_DIAG
+#define GP_SYNC() do { const u64 tb_ = clock64(); __syncthreads(); if ((threadIdx.x & 63) == 0) { ctl->barw[threadIdx.x >> 6] += clock64() - tb_; ++ctl->barn[threadIdx.x >> 6]; } } while (0)
+#else
+#define GP_SYNC() __syncthreads()
+#endif
 #ifdef GP_DIAG
 #define GP_STAMP(var) do { if (threadIdx.x == 0) var = wall_clock64(); } while (0)
 #define GP_ACCUM(acc, t0, t1) do { if (threadIdx.x == 0) acc += (t1) - (t0); } while (0)
@@ -891,7 +903,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         // scratch LDS did the same at the price of clearing and scanning 4096 words per row.)
         if (tid < 64) ctl->bcnt[tid] = 0;
         if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
-        __syncthreads();
+        GP_SYNC();
         for (u32 base = 0; base < seg_len; base += 8 * BLOCK) {              // 8 loads in flight per thread
             double vv[8];
 #pragma unroll
@@ -907,21 +919,21 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
         }
-        __syncthreads();
+        GP_SYNC();
         if (wave == 0) {
             const u32 incl = wave_incl_scan(ctl->bcnt[lane], lane);          // records >= 2^-lane
             const u64 m = __ballot(incl >= K);
             if (lane == 0) ctl->tk_bin = m ? (u32)__ffsll((long long)m) - 1u : 0xFFFFFFFFu;
         }
-        __syncthreads();
+        GP_SYNC();
         const u32 binade = ctl->tk_bin;
-        __syncthreads();
+        GP_SYNC();
         const u32 bin = binade >= 63u ? 0u : 1023u - binade;                 // biased exponent of tau; 0 = no threshold
         if (bin != 0xFFFFFFFFu && bin != 0) {
             const double tau = __longlong_as_double((long long)((u64)bin << 52));
             const double thr = tau / (double)n_levels * 0.99999;
             for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
-            __syncthreads();
+            GP_SYNC();
             GP_SUB(0);
             bool ok = true;
             constexpr int UA = 8;                                                 // records in flight per thread
@@ -938,7 +950,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                     if (vv[u] >= thr) ok &= lds_claim(akeys, CA, kk[u]);
             }
             if (!ok) ctl->ovf = 1;
-            __syncthreads();
+            GP_SYNC();
             if (!ctl->ovf) {
                 for (u32 base = 0; base < n_log; base += UA * BLOCK) {           // pass B: add
                     int kk[UA]; double vv[UA];
@@ -958,16 +970,16 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                 }
                 if (tid < 64) ctl->bcnt[tid] = 0;                        // binade counters of the first digit (emit_candidates)
                 if (tid == 0) ctl->tk_wide = 0;
-                __syncthreads();
+                GP_SYNC();
                 GP_SUB(1);
                 emit_candidates(live_nodes);
-                __syncthreads();
+                GP_SYNC();
                 GP_SUB(2); GP_SUB_COUNT(11, 1);
                 pruned_done = true;
             } else {
-                __syncthreads();
+                GP_SYNC();
                 if (tid == 0) ctl->ovf = 0;              // too many live nodes for one table: full path
-                __syncthreads();
+                GP_SYNC();
             }
         }
     }
@@ -991,7 +1003,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
         u32 part = 0, parts = P0;
         for (;;) {
             for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
-            __syncthreads();
+            GP_SYNC();
             GP_SUB(0); GP_SUB_COUNT(8, 1);
             bool ok = true;
             for (u32 base = 0; base < n_log && ok; base += 4 * BLOCK) {
@@ -1009,18 +1021,18 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                         ok &= res_add_lds(akeys, avals, CA, kk[u], vv[u]);
             }
             if (!ok) ctl->ovf = 1;
-            __syncthreads();
+            GP_SYNC();
             GP_SUB(1);
             if (ctl->ovf) {
-                __syncthreads();
+                GP_SYNC();
                 if (tid == 0) ctl->ovf = 0;
                 if (parts < 0x20000000u) { part *= 2; parts *= 2; continue; }     // descend into the left half
                 if (tid == 0) ctl->fail = 1;         // cannot happen for a sane hash; reported, not silent
-                __syncthreads();
+                GP_SYNC();
                 break;
             }
             emit_candidates(support);
-            __syncthreads();
+            GP_SYNC();
             GP_SUB(2);
             while (parts > P0 && (part & 1u)) { part >>= 1; parts >>= 1; }       // right child done => parent done
             ++part;                                                              // sibling / next top-level partition
@@ -1042,7 +1054,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
     // ---- 2. select
     if (m <= K) {
         for (u32 i = tid; i < m; i += BLOCK) sel[i] = cand[i];
-        __syncthreads();
+        GP_SYNC();
     } else {
         const Cand* cur = cand;     // current candidate array: HBM, or `big` in LDS after compaction
         u32 cur_n = m;
@@ -1055,14 +1067,14 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             const bool binades = depth == 0 && !ctl->tk_wide;          // first digit counted in 64 binade counters
             if (!binades) {
                 for (u32 i = tid; i < kTopkBins; i += BLOCK) hist[i] = 0;
-                __syncthreads();
+                GP_SYNC();
                 for (u32 i = tid; i < cur_n; i += BLOCK) {
                     const Cand c = cur[i];
                     if (pre_eq(cand_prefix(c, depth), prefix))
                         __hip_atomic_fetch_add(&hist[cand_digit(c, depth)], 1u,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                __syncthreads();
+                GP_SYNC();
             }
             GP_SUB(3); GP_SUB_COUNT(compacted ? 10 : 9, 1);
             if (wave == 0) {
@@ -1074,13 +1086,13 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                     if (lane == bl) { ctl->tk_bin = 1023u - (u32)bl; ctl->tk_above = incl - c; ctl->tk_count = c; }
                 } else topk_pick_bin(ctl, hist, want, lane);
             }
-            __syncthreads();
+            GP_SYNC();
             GP_SUB(4);
             prefix = pre_push(prefix, depth, ctl->tk_bin);
             want -= ctl->tk_above;
             const u32 cnt = ctl->tk_count;
             ++depth;
-            __syncthreads();
+            GP_SYNC();
             if (cnt == want) { take_all = true; break; }
             if (cnt <= (u32)kBucketCap || depth == 8) break;
             if (!compacted && cnt <= big_cap) {
@@ -1099,10 +1111,10 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                     const u32 bi = wave_alloc1(&ctl->n_bucket, is_b, lane);
                     if (is_b) big[bi] = c;
                 }
-                __syncthreads();
+                GP_SYNC();
                 cur = big; cur_n = cnt; compacted = true;
                 if (tid == 0) ctl->n_bucket = 0;
-                __syncthreads();
+                GP_SYNC();
                 GP_SUB(5);
             }
         }
@@ -1122,7 +1134,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             const u32 bi = wave_alloc1(&ctl->n_bucket, is_b, lane);
             if (is_b && bi < (u32)kBucketCap) tie[bi] = c;
         }
-        __syncthreads();
+        GP_SYNC();
         if (!take_all) {
             const u32 nb = min(ctl->n_bucket, (u32)kBucketCap);
             const u32 n_sel0 = ctl->n_sel;                     // == K - want
@@ -1132,7 +1144,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                 for (u32 j = 0; j < nb; ++j) rank += cand_better(tie[j], mine) ? 1u : 0u;
                 if (rank < want) sel[n_sel0 + rank] = mine;
             }
-            __syncthreads();
+            GP_SYNC();
         }
     }
     GP_SUB(6);
@@ -1157,8 +1169,11 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
 // Register budget: 1024 threads = 4 waves/SIMD = 128 VGPRs.  The 512- and 256-thread forms are
 // built for the SAME 4 waves/SIMD so that 2 (resp. 4) workgroups can share a CU and overlap
 // one row's barriers and memory stalls with another row's work.
+#ifndef GP_MINW_512
+#define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
+#endif
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
+__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MINW_512 : 4) gfpush_kernel(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctl* ctl   = (Ctl*)smem;
@@ -1183,11 +1198,13 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
 #ifdef GP_DIAG
     u64 gp_sub_t = 0; u64 gp_sub_acc[16];
     for (int i = 0; i < 16; ++i) gp_sub_acc[i] = 0;
+    if (tid < 16) { ctl->barw[tid] = 0; ctl->barn[tid] = 0; }
+    const u64 wave_t0 = clock64();
 #endif
     const int L = p.n_coef - 1;
 
     for (;;) {
-        __syncthreads();
+        GP_SYNC();
         if (tid == 0) {
             ctl->row = (long long)__hip_atomic_fetch_add(&p.counters[kQueue], 1ull, __ATOMIC_RELAXED,
                                                          __HIP_MEMORY_SCOPE_AGENT);
@@ -1195,7 +1212,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             ctl->n_cand = 0; ctl->fail = 0; ctl->ovf = 0;
             ctl->n_sel = 0; ctl->n_bucket = 0;
         }
-        __syncthreads();
+        GP_SYNC();
         const long long row = ctl->row;
         if (row >= p.n_seeds) break;
         const int seed = p.seeds[row];
@@ -1259,7 +1276,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                 }
             }
             cur = 1;
-            __syncthreads();                            // push entries / fail flag visible to every wave
+            GP_SYNC();                            // push entries / fail flag visible to every wave
         }
         for (int lvl = 1; lvl <= L; ++lvl) {
             const double c = p.coef[lvl];
@@ -1288,6 +1305,9 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
             PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
             const u32 snap_log = ctl->log_count;          // first log record of this level
+#ifdef GP_DIAG
+            const u64 lv_e0 = tk_expand, lv_s0 = tk_scan; u32 lv_passes = 0;
+#endif
             // Counters this level's SCAN will fill.  The other parity is what the threads have just
             // read (previous level), this one was last read two levels ago: thread 0 may clear it
             // now, and SCAN only starts after the end-of-EXPAND barrier.  No barrier needed here.
@@ -1300,7 +1320,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                 parts = 1;
                 if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; }
                 cap = (u32)min(p.resg_cap, max((u64)kMinCap, 2 * need));
-                __syncthreads();
+                GP_SYNC();
             }
             // Hash partitions (q, P) of the level's targets, refined in place on overflow exactly
             // like the aggregation partitions of topk_row (nothing to undo: a partition is
@@ -1319,7 +1339,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                 const u32 stride = (u32)min((u64)0xFFFFFFFFu, p.bucket_cap / P);
                 if (tid < 64) ctl->bcnt[tid] = 0;
                 if (tid == 0) ctl->bovf = 0;
-                __syncthreads();
+                GP_SYNC();
                 GP_STAMP(t0);
                 for_each_edge<BLOCK>(p, push_cur, n_push_cur, n_long_cur, log2g, [&](int v, double share) {
                     const u32 bk = slot_of(hash_b((u32)v), P);
@@ -1327,10 +1347,10 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     if (i < stride) { ResRec r; r.key = v; r.pad = 0; r.val = share; bucket[(u64)bk * stride + i] = r; }
                     else ctl->bovf = 1;
                 });
-                __syncthreads();
+                GP_SYNC();
                 GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
                 if (ctl->bovf) use_buckets = false;
-                else { if (tid < 64 && (u32)tid < P) ctl->boff[tid] = (u32)tid * stride; __syncthreads(); }
+                else { if (tid < 64 && (u32)tid < P) ctl->boff[tid] = (u32)tid * stride; GP_SYNC(); }
             }
             if (use_buckets) {
                 // one insert pass per bucket, refined in place (q of Q sub-partitions) if it still overflows
@@ -1339,6 +1359,9 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     u32 q = 0, Q = 1;
                     for (;;) {
                         GP_STAMP(t0);
+#ifdef GP_DIAG
+                        ++lv_passes;
+#endif
                         const u32 want = b * Q + q, fine = P * Q;
                         bool ok = true;
                         for (u32 base = lo; base < hi; base += 4 * BLOCK) {
@@ -1357,19 +1380,19 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                         if (tid == 0 && has_dang_cur && slot_of(hash_b((u32)seed_key), fine) == want)       // graph.h:92
                             ok &= res_add_lds(lkeys, lvals, cap, seed_key, dang_cur);
                         if (!ok) ctl->ovf = 1;
-                        __syncthreads();
+                        GP_SYNC();
                         GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
                         if (ctl->ovf) {
                             for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
-                            __syncthreads();
+                            GP_SYNC();
                             if (tid == 0) ctl->ovf = 0;
-                            if (Q < (1u << 20)) { q *= 2; Q *= 2; __syncthreads(); continue; }
+                            if (Q < (1u << 20)) { q *= 2; Q *= 2; GP_SYNC(); continue; }
                             if (tid == 0) ctl->fail = 1;
-                            __syncthreads();
+                            GP_SYNC();
                             break;
                         }
                         scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
-                        __syncthreads();
+                        GP_SYNC();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2);
                         if (ctl->fail) break;
                         while (Q > 1 && (q & 1u)) { q >>= 1; Q >>= 1; }
@@ -1382,6 +1405,9 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                     u32 part = 0, np = parts;
                     for (;;) {
                         GP_STAMP(t0);
+#ifdef GP_DIAG
+                        ++lv_passes;
+#endif
                         {
                             if (BLOCK == 512 && direct) {
                                 expand_level<BLOCK, true, BLOCK == 512>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
@@ -1400,31 +1426,31 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                             }
                             }
                         }
-                        __syncthreads();
+                        GP_SYNC();
                         GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1); if (!in_lds) GP_ACCUM(tk_expand_hbm, t0, t1);
                         if (ctl->fail) break;
                         if (ctl->ovf) {
                             // this partition did not fit: wipe the table and split it in two
                             for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
-                            __syncthreads();
+                            GP_SYNC();
                             if (tid == 0) ctl->ovf = 0;
-                            if (np < 0x20000000u) { part *= 2; np *= 2; __syncthreads(); continue; }
+                            if (np < 0x20000000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
                             if (tid == 0) ctl->fail = 1;
-                            __syncthreads();
+                            GP_SYNC();
                             break;
                         }
                         if (in_lds) {
                             scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
 #ifdef GP_DIAG
                             if (p.diag_flags & 4) {                  // a second walk over the (now empty) table: cost of stage (a) alone
-                                __syncthreads();
+                                GP_SYNC();
                                 scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
                             }
 #endif
                         } else {
                             scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push);
                         }
-                        __syncthreads();
+                        GP_SYNC();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
                         if (ctl->fail) break;
                         while (np > parts && (part & 1u)) { part >>= 1; np >>= 1; }   // right child done => parent done
@@ -1434,6 +1460,17 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
                 }
             }
             if (tid == 0) stat_add(ctl, in_lds ? sLds : sGlb, 1);
+#ifdef GP_DIAG
+            if (tid == 0) {
+                u64* dx = p.counters + kDiagX0 + 16 + 6 * min(lvl, 15);
+                __hip_atomic_fetch_add(dx + 0, tk_expand - lv_e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dx + 1, tk_scan - lv_s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dx + 2, (u64)e_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dx + 3, (u64)(ctl->log_count - snap_log), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dx + 4, (u64)(n_push_cur + n_long_cur), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dx + 5, (u64)lv_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#endif
             {
                 const u32 lvl_len = ctl->log_count - snap_log;      // read after the level's last barrier
                 n_levels = lvl + 1;
@@ -1445,7 +1482,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             dang_cur = nx->dangling; has_dang_cur = nx->n_dangling != 0;
             cur ^= 1;
         }
-        __syncthreads();
+        GP_SYNC();
         if (ctl->fail) {
             // Leave the row unwritten and report it (GP_ERR_OVERFLOW).  Restore clean tables so
             // that later rows of this workgroup are unaffected.
@@ -1459,7 +1496,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
         if (!(p.diag_flags & 1))
 #endif
         topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, seg_begin, seg_len, n_levels, 0 GP_SUB_ARGS);
-        __syncthreads();
+        GP_SYNC();
         if (ctl->fail && tid == 0) stat_add(ctl, sFailed, 1);
         GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);
         // top-K used the table region as scratch: restore the empty LDS table
@@ -1467,7 +1504,7 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
     }
 
     // flush statistics: one atomic per counter per workgroup
-    __syncthreads();
+    GP_SYNC();
     if (tid == 0) {
         const Counter dst[sNumStats] = { kPushes, kEdges, kFrontier, kDegLookups, kFilled, kSupport, kLdsLevels, kGlobalLevels, kFailedRows };
 #pragma unroll
@@ -1485,6 +1522,13 @@ __global__ void __launch_bounds__(BLOCK, 4) gfpush_kernel(const KParams p)
             __hip_atomic_fetch_add(&p.counters[kDiag0 + i], gp_sub_acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
+#ifdef GP_DIAG
+    if ((tid & 63) == 0) {
+        __hip_atomic_fetch_add(&p.counters[kDiagX0 + 0], clock64() - wave_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kDiagX0 + 1], ctl->barw[tid >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kDiagX0 + 2], (u64)ctl->barn[tid >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 }
 
 // Fills the per-workgroup HBM residue tables with empty records (a byte memset cannot: val must be 0).

@@ -190,6 +190,11 @@ int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim
  * above *node_mask; packs them first if that has not happened yet) */
 int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indices, uint32_t* node_mask, void* stream);
 
+/* internal: the extended counters of the diagnostic build (-DGP_DIAG; all 0 in the product library): [0] wave
+ * cycles, [1] cycles the waves waited at workgroup barriers, [2] barriers passed, [16 + 6*level + k] per level
+ * (k = 0 expand ticks, 1 scan ticks, 2 edges, 3 frontier nodes, 4 push-list entries, 5 table passes); n <= 128 */
+int gp_internal_diag_counters(gp_graph* g, int64_t* out, int n);
+
 /* internal: lets the second translation unit report through gp_last_error (not for callers) */
 void gp_internal_set_error(int status, const char* where, const char* detail);
 

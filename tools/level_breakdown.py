@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-level time and work of the GFPush kernel + the share of wave time spent at workgroup barriers
+(diagnostic build only: `GRANDPLUS_DIAG=1 python tools/level_breakdown.py [workload ...]`)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+from grand_plus_amd import Graph  # noqa: E402
+from grand_plus_amd.recipes import RECIPES  # noqa: E402
+
+
+def main():
+    if os.environ.get("GRANDPLUS_DIAG") != "1":
+        sys.exit("set GRANDPLUS_DIAG=1")
+    names = sys.argv[1:] or ["mag"]
+    for name in names:
+        source, rkey, _ = bench.WORKLOADS[name]
+        ip, ix = bench.load_graph(source, os.cpu_count() or 8)
+        r = RECIPES[rkey]
+        S = 4096 if name == "amazon2m" else 16384
+        seeds = torch.from_numpy(bench.make_seeds(source, len(ip) - 1, S).astype(np.int32)).cuda()
+        g = Graph(ip, ix, 0)
+        for o in os.environ.get("GP_OPTS", "").split(","):
+            if o:
+                k, v = o.split("="); g.set_option(k, int(v))
+        for _ in range(2):
+            g.reset_stats(); g.gfpush_device(seeds, r.coef(), r.rmax, r.top_k); torch.cuda.synchronize()
+        st = g.stats(); dx = g.diag_counters(); rows = st["rows"]; tot = st["diag_ticks_total"]
+        print(f"{name}: kernel {st['kernel_ms']:.2f} ms, {tot / rows / 100:.1f} us/row/wg; scan {st['diag_ticks_scan'] / tot:.3f} "
+              f"expand {st['diag_ticks_expand'] / tot:.3f} topk {st['diag_ticks_topk'] / tot:.3f}; "
+              f"barrier wait {dx[1] / max(dx[0], 1):.3f} of wave cycles, {dx[2] / 16 / rows:.1f} barriers/row "
+              f"({dx[1] / max(dx[2], 1):.0f} cyc waited per wave per barrier); wave cycles/row {dx[0] / 16 / rows:.0f}", flush=True)
+        for lvl in range(1, 16):
+            e, s, ed, nd, pe, ps = dx[16 + 6 * lvl:16 + 6 * lvl + 6]
+            if ps == 0:
+                continue
+            print(f"   level {lvl:2d}: expand {e / rows / 100:6.2f} us  scan {s / rows / 100:6.2f} us  edges {ed / rows:8.1f}  "
+                  f"nodes {nd / rows:8.1f}  entries {pe / rows:7.1f}  passes {ps / rows:5.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

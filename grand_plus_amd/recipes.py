@@ -12,16 +12,29 @@ from dataclasses import dataclass
 import numpy as np
 
 
-def make_coef(prop_mode: str, order: int, alpha: float = 0.2) -> np.ndarray:
+def make_coef(prop_mode: str, order: int, alpha: float = 0.2, t: float | None = None) -> np.ndarray:
     """Coefficient vector of length ``order + 1`` normalised to sum 1.
 
     Mirrors `model.py:255-267`: ppr -> alpha*(1-alpha)^i built by repeated
     multiplication (so the floating-point values are those of the reference),
     avg -> ones, single -> one-hot on the last level; then ``/ sum``.
+
+    ``heat`` is the truncated heat-kernel weighting BASELINE.json's north_star names next to ppr and
+    avg: coef[k] = e^-t * t^k / k! for k = 0..order (diffusion time ``t``; ``alpha`` is read as ``t``
+    when ``t`` is not given, so a `Recipe` carries it in the same field), built by the recurrence
+    c[k] = c[k-1] * t / k and normalised like the other modes (`model.py:267`).  The reference's glue
+    has no such branch (its `else` raises, `model.py:265`); `gfpush_omp` itself takes any coef.
     """
     if order < 0:
         raise ValueError("order must be >= 0")
-    if prop_mode == "avg":
+    if prop_mode == "heat":
+        tt = float(alpha if t is None else t)
+        if not (tt > 0.0) or not np.isfinite(tt):
+            raise ValueError("heat-kernel diffusion time t must be finite and > 0")
+        coef = [float(np.exp(-tt))]
+        for k in range(1, order + 1):
+            coef.append(coef[-1] * tt / k)
+    elif prop_mode == "avg":
         coef = list(np.ones(order + 1, dtype=np.float64))
     elif prop_mode == "ppr":
         coef = [alpha]
@@ -73,6 +86,10 @@ RECIPES = {
     ("mag", "ppr"): Recipe("mag", "ppr", 10, 0.2, 1e-5, 32),
     ("mag", "avg"): Recipe("mag", "avg", 10, 0.2, 1e-5, 32),
     ("mag", "single"): Recipe("mag", "single", 2, 0.2, 1e-5, 32),
+    # truncated heat kernel (north_star; no scripts/run_*.sh line): `alpha` holds the diffusion time t,
+    # order / rmax / top_k follow the dataset's ppr line
+    ("pubmed", "heat"): Recipe("pubmed", "heat", 6, 3.0, 1e-5, 16),
+    ("mag", "heat"): Recipe("mag", "heat", 10, 4.0, 1e-5, 32),
 }
 
 

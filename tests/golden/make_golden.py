@@ -86,9 +86,31 @@ def run_reference(ref, indptr, indices, seeds, coef, rmax, K):
     return row, col, val
 
 
+def heat_cases(ref):
+    """Heat-kernel coefficients (north_star; recipes.make_coef("heat")) through the REAL reference's
+    gfpush_omp, which takes any coef (graph.h:63-64,90): Pubmed graph and the 100k-node synthetic shape."""
+    adj, tr, va, te = citation_graph("pubmed")
+    indptr, indices, seeds = caller_inputs(adj, tr, va, te)
+    out = {}
+    for tag, (ip, ix, sd), key in (("pubmed", (indptr, indices, seeds[:256]), ("pubmed", "heat")),
+                                   ("small", synth.shape_csr("small") + (synth.seeds(synth.SHAPES["small"].n_nodes, 256).astype(np.int64),),
+                                    ("mag", "heat"))):
+        r = RECIPES[key]
+        coef = r.coef()
+        row, col, val = run_reference(ref, ip, ix, sd, coef, r.rmax, r.top_k)
+        out[f"{tag}_seeds"], out[f"{tag}_coef"] = sd, coef
+        out[f"{tag}_params"] = np.array([r.rmax, r.top_k, len(sd), r.order, r.alpha], dtype=np.float64)
+        out[f"{tag}_row"], out[f"{tag}_col"], out[f"{tag}_val"] = row, col, val
+        print("heat", tag, "filled", int((val > 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "heat.npz"), **out)
+
+
 def main():
     ref = pyoracle.load_reference_module()
     assert ref is not None, "oracle/_ref is not built (make -C oracle)"
+    if "--only-heat" in sys.argv:          # adds tests/golden/heat.npz without rewriting the other fixtures
+        return heat_cases(ref)
+    heat_cases(ref)
     meta = {"generator": "tests/golden/make_golden.py", "reference": "oracle/_ref (compiled /root/reference/precompute/propagation.cpp)",
             "cases": {}, "synthetic_checksums": {}}
 

@@ -114,6 +114,21 @@ def test_reference_golden_through_dropin_module(name, mode):
     assert abs(a.sum() - b.sum()) < 1e-9 * max(1.0, b.sum())
 
 
+@pytest.mark.parametrize("tag", ["pubmed", "small"])
+def test_reference_golden_heat_kernel(tag):
+    """Truncated heat-kernel coefficients (north_star; recipes.make_coef("heat")) through the drop-in module,
+    against the compiled reference's rows (tests/golden/heat.npz)."""
+    from precompute import propagation
+    from golden_cases import heat_case as _heat_case
+    indptr, indices, seeds, coef, rmax, K, exp = _heat_case(tag)
+    g = propagation.Graph(indptr, indices, 0)
+    n = len(seeds)
+    row = np.zeros(n * K, np.int32); col = np.zeros(n * K, np.int32); val = np.zeros(n * K, np.float64)
+    g.gfpush_omp(seeds, row, col, val, coef, rmax, K)
+    rep = _assert_parity(seeds, K, (row, col, val), exp)
+    assert rep.max_rel_err < 1e-12
+
+
 @pytest.mark.parametrize("tag,shape", [("synth_tiny_pubmed_ppr", "tiny"), ("synth_small_mag_ppr", "small"),
                                        ("synth_small_reddit_avg", "small")])
 def test_reference_golden_synthetic(tag, shape):

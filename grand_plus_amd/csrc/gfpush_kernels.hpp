@@ -59,7 +59,9 @@ constexpr int    kSplitLen   = 128;     // a long CSR range is split into chunks
 constexpr int    kLongLen    = 64;      // upper limit of KParams::long_len (ranges longer than long_len are expanded by a whole wave)
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
-constexpr int    kCtlBytes   = 1280;    // control block at the start of dynamic LDS
+constexpr int    kFlatW      = 4;       // EXPAND: 64-edge windows a wave keeps in flight (column loads issued together)
+constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic LDS ...
+constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (expand_flat)
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
 constexpr u32    kBucketMin  = 4;       // levels needing at least this many partitions bucket their edges in HBM once
@@ -196,6 +198,7 @@ __device__ __forceinline__ u32 slot_of(u32 h, u32 cap) { return (u32)(((u64)h * 
 // Home slot in an LDS table of `cap` slots.  Homes lie in [0, cap - kProbeSpan): a probe sequence then
 // never leaves [0, cap), so the probing loops need no wrap-around (4 VALU per probe); 2 % of a full
 // table is the price.  Every LDS table has cap >= kMinCap > kProbeSpan.
+static_assert(kFlatW == 4, "expand_flat clears its flags with one 32-bit store per lane");
 static_assert(kMinCap > 2 * kProbeSpan, "every LDS table must be much larger than the probe span");
 __device__ __forceinline__ u32 home_lds(u32 k, u32 cap) { return slot_of(hash_a(k), cap - kProbeSpan); }
 
@@ -213,6 +216,17 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 x, int lane) {
         const u32 y = __shfl_up(x, d);
         if (lane >= d) x += y;
     }
+    return x;
+}
+// Inclusive prefix sum over the wave with DPP row shifts / broadcasts: 6 adds and no LDS round trip
+// (__shfl_up goes through ds_bpermute, i.e. six dependent LDS-crossbar latencies).
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8   -> scan inside each row of 16
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
     return x;
 }
 __device__ __forceinline__ u32 wave_suffix_scan(u32 x, int lane) {   // sum over lanes >= lane
@@ -742,14 +756,82 @@ __device__ __forceinline__ void expand_list(const KParams& p, u32* flag, int* lk
     }
 }
 
+// EXPAND, flattened: ONE LANE PER EDGE.  A wave takes a batch of up to 64 consecutive push-list entries (lane j
+// owns entry j), prefix-sums their lengths, and walks the batch's T edges in windows of 64: lane i of a window
+// handles edge q = t + i, whatever entry it belongs to.  So every column load and every table insert runs with
+// all 64 lanes busy (the per-entry lane groups of expand_list sat at ~45 % because range lengths vary 1..32):
+// ~2.4x fewer wave-instructions per edge in a phase that is instruction-issue bound while it runs.
+// Edge -> entry: the entries starting inside the window flag their first edge in a per-wave byte array (LDS
+// operations of one wave execute in order: no barrier), a ballot turns the flags into a mask M, and the owner of
+// edge i is entry `first + popcount(M & lanes <= i)` -- mbcnt, no search.  The owner's (start - prefix, share)
+// are then pulled with ds_bpermute.  kFlatW windows are handled per step so that their column loads are in
+// flight together.
+template <int BLOCK, bool IN_LDS, bool DIRECT>
+__device__ __forceinline__ void expand_flat(const KParams& p, u32* flag, unsigned char* wscr, int* lkeys, double* lvals, ResRec* resg, u32 cap,
+                                            const PushEntry* list, long long stride_sign, u32 n_entries,
+                                            u32 part, u32 parts, bool dry = false)
+{
+    const int lane = threadIdx.x & 63;
+    constexpr u32 kWaves = BLOCK / 64;
+    constexpr int W = kFlatW;
+    const u32 wave = (u32)threadIdx.x >> 6;
+    const u32 per = min(64u, (n_entries + kWaves - 1) / kWaves);         // entries per wave and round
+    for (u32 base = wave * per; base < n_entries; base += kWaves * per) {
+        const u32 cnt = min(per, n_entries - base);
+        int start = 0; u32 len = 0; double share = 0.0;
+        if ((u32)lane < cnt) {
+            const PushEntry pe = list[stride_sign * (long long)(base + (u32)lane)];
+            start = pe.start; len = (u32)pe.len; share = dry ? 0.0 : pe.share;   // dry: GP_DIAG's value-neutral second pass
+        }
+        const u32 incl = wave_incl_scan_dpp(len);
+        const u32 excl = incl - len;                                     // first edge of my entry inside the batch
+        const u32 T = (u32)__builtin_amdgcn_readlane((int)incl, 63);     // edges of the batch
+        const int rel = start - (int)excl;                               // column index of edge q = rel(owner) + q   graph.h:97
+        for (u32 t = 0; t < T; t += 64u * W) {
+            *(u32*)(wscr + 4 * lane) = 0u;                               // clears the 64*W flags (W == 4)
+            if (len != 0 && excl > t && excl < t + 64u * W) wscr[excl - t] = 1;
+            u32 before = (u32)__popcll(__ballot(len != 0 && excl <= t)) - 1u;    // owner of edge t (wave-uniform)
+            int v[W]; double sh[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const bool mine = wscr[64 * w + lane] != 0;
+                const u64 M = __ballot(mine);
+                const u32 e = before + lane_prefix(M) + (mine ? 1u : 0u);        // lane that owns my edge
+                before += (u32)__popcll(M);
+                const int rel_e = __shfl(rel, (int)e);
+                sh[w] = __shfl(share, (int)e);
+                const u32 q = t + 64u * (u32)w + (u32)lane;
+                v[w] = q < T ? p.indices[rel_e + (int)q] : -1;                      // graph.h:97
+            }
+#ifdef GP_DIAG
+            if (dry && (p.diag_flags & 8)) {                 // timing attribution: the dry pass loads but does not insert
+#pragma unroll
+                for (int w = 0; w < W; ++w) if (v[w] == 0x7FFFFFFF) *flag = 1u;
+                continue;
+            }
+#endif
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                if (v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part))
+                    res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v[w], sh[w], flag);   // graph.h:98
+        }
+    }
+}
+
 template <int BLOCK, bool IN_LDS, bool DIRECT = false>
 __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
                                              ResRec* resg, u32 cap, const PushEntry* push,
                                              u32 n_short, u32 n_long, int log2g, u32 part, u32 parts, bool dry = false)
 {
     u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
+#ifdef GP_EXPAND_GROUPS
     if (n_long)  expand_list<BLOCK, IN_LDS, 2, DIRECT>(p, flag, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts, dry);
     if (n_short) expand_list<BLOCK, IN_LDS, 4, DIRECT>(p, flag, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts, dry);
+#else
+    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * (threadIdx.x >> 6);
+    if (n_long)  expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, part, parts, dry);
+    if (n_short) expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push, 1, n_short, part, parts, dry);
+#endif
 }
 
 // ---------------------------------------------------------------- bucketed levels

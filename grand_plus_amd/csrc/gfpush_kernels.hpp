@@ -118,10 +118,19 @@ enum Stat { sPush = 0, sEdges, sFront, sDeg, sFilled, sSupport, sLds, sGlb, sFai
 __device__ __forceinline__ void stat_add(Ctl* ctl, int which, u64 n) {
     __hip_atomic_fetch_add(&ctl->st[which], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ u32 wave_sum32(u32 x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_down(x, d);
-    return x;                                   // valid in lane 0
+// Inclusive prefix sum over the wave with DPP row shifts / broadcasts: 6 adds and no LDS round trip
+// (__shfl_up / __shfl_down go through ds_bpermute, i.e. six dependent LDS-crossbar latencies).
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8   -> scan inside each row of 16
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
+    return x;
+}
+__device__ __forceinline__ u32 wave_sum32(u32 x) {           // sum over the wave, valid in every lane (all 64 lanes must call)
+    return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63);
 }
 
 enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
@@ -210,25 +219,7 @@ template <class T> __device__ __forceinline__ void st_l2(T* p, T v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ u32 wave_incl_scan(u32 x, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    return x;
-}
-// Inclusive prefix sum over the wave with DPP row shifts / broadcasts: 6 adds and no LDS round trip
-// (__shfl_up goes through ds_bpermute, i.e. six dependent LDS-crossbar latencies).
-__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x) {
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8   -> scan inside each row of 16
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
-    return x;
-}
+__device__ __forceinline__ u32 wave_incl_scan(u32 x, int /*lane*/) { return wave_incl_scan_dpp(x); }
 __device__ __forceinline__ u32 wave_suffix_scan(u32 x, int lane) {   // sum over lanes >= lane
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -681,11 +672,8 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
     // atomics per step would serialise)
     if (lane == 0 && tot) stat_add(ctl, sFront, tot);
     if (do_push && tot) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            e_all += __shfl_down(e_all, d); e_sht += __shfl_down(e_sht, d);
-            st_push += __shfl_down(st_push, d); st_edges += __shfl_down(st_edges, d); st_deg += __shfl_down(st_deg, d);
-        }
+        e_all = wave_sum32(e_all); e_sht = wave_sum32(e_sht);
+        st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
         if (lane == 0) {
             if (e_all) {
                 __hip_atomic_fetch_add(&nx->e_next, e_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

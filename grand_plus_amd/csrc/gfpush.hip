@@ -361,17 +361,19 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     // a launch on a DIFFERENT stream first waits for the previous one
     if (g->launched && g->last_stream != s) HIP_TRY(hipStreamSynchronize(g->last_stream));
 
-    // Geometry.  Default: one 1024-thread workgroup per CU owning all 160 KB of LDS.  Two 512-thread
-    // workgroups per CU (80 KB each) overlap one row's barriers and memory stalls with another row's
-    // work; they win when the levels of a row are small next to the half-size table, and lose when a
-    // level then needs hash partitions.  Chosen automatically for (a) graphs so small that every level
-    // fits the half table (N <= 0.75 * slots(80 KB); Cora +16 %) and (b) sparse graphs, nnz < 8 N, whose
-    // frontiers stay small (Pubmed: +14 % ppr, +45 % avg, +90 % single; Citeseer +60 %).  Denser shapes
-    // keep 1 x 1024 (Reddit-shape loses 16 % with two workgroups, MAG-shape 1 %): tools/shape_sweep.py.
+    // Geometry.  Two 512-thread workgroups per CU (80 KB of LDS each) or one 1024-thread workgroup owning all
+    // 160 KB.  All waves of a workgroup move through a row's phases together, so they wait for memory together
+    // and compete for issue slots together; a second, independent workgroup on the CU fills those gaps (one
+    // row's barriers, memory stalls and TOP-K overlap the other row's inserts).  The half-size table costs extra
+    // hash partitions on the biggest levels, which the one-lane-per-edge EXPAND made cheap (a partition pass
+    // re-reads and filters at ~25 wave-instructions per 64 edges).  Measured on MI355X, 65 536 rows (tools/exp_run2.sh):
+    // MAG-shape +13 %, Reddit-shape +15 %, Pubmed +20 %, Cora +74 %; the Amazon2M recipe (rmax 1e-6: levels of
+    // ~100 k edges, 14+ partitions even with 160 KB) loses 36 % and keeps 1 x 1024, as does any rmax < 5e-6 on a
+    // graph that is neither tiny nor sparse.
     const bool auto_shape = g->block_threads == 0 && g->lds_bytes == 0;
     const bool tiny = (double)g->n_nodes <= 0.75 * (double)((80 * 1024 - kCtlBytes) / 12);
     const bool sparse = g->nnz < 8 * g->n_nodes;
-    bool two_per_cu = auto_shape && K <= 256 && (tiny || sparse);
+    bool two_per_cu = auto_shape && K <= 256 && (tiny || sparse || rmax >= 5e-6);
     int block_threads = 0, lds_bytes = 0, n_wg = 0;
     u32 lds_slots = 0;
     for (;;) {

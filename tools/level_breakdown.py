@@ -34,6 +34,10 @@ def main():
               f"expand {st['diag_ticks_expand'] / tot:.3f} topk {st['diag_ticks_topk'] / tot:.3f}; "
               f"barrier wait {dx[1] / max(dx[0], 1):.3f} of wave cycles, {dx[2] / 16 / rows:.1f} barriers/row "
               f"({dx[1] / max(dx[2], 1):.0f} cyc waited per wave per barrier); wave cycles/row {dx[0] / 16 / rows:.0f}", flush=True)
+        print(f"   per row (us): prologue {dx[4] / rows / 100:.2f}  level0 {dx[5] / rows / 100:.2f}  level-loop outside expand/scan {dx[6] / rows / 100:.2f}  "
+              f"table restore {dx[7] / rows / 100:.2f}  topk {st['diag_ticks_topk'] / rows / 100:.2f}", flush=True)
+        names = ["agg_init", "agg_insert", "agg_scan", "sel_hist", "sel_pick", "sel_compact", "sel_collect", "final"]
+        print("   topk sub-phases (us/row):", {n: round(st["diag_sub"][i] / rows / 100, 2) for i, n in enumerate(names)}, flush=True)
         for lvl in range(1, 16):
             e, s, ed, nd, pe, ps = dx[16 + 6 * lvl:16 + 6 * lvl + 6]
             if ps == 0:

@@ -64,7 +64,10 @@ constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (expand_flat)
 constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
-constexpr u32    kBucketMin  = 4;       // levels needing at least this many partitions bucket their edges in HBM once
+#ifndef GP_BUCKET_MIN
+#define GP_BUCKET_MIN 3
+#endif
+constexpr u32    kBucketMin  = GP_BUCKET_MIN;       // levels needing at least this many partitions bucket their edges in HBM once
                                         // instead of re-reading and hash-filtering every CSR range once per partition
 constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many slots reports overflow
 constexpr u32    kProbeSpan  = kMaxProbe * (kMaxProbe + 1) / 2;   // furthest a triangular probe sequence can walk (300 slots)
@@ -605,7 +608,10 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         // (d) the nodes that may push: V x 64 per step, their indptr loads in flight together
-        constexpr int V = 2;
+#ifndef GP_SCAN_V
+#define GP_SCAN_V 2
+#endif
+        constexpr int V = GP_SCAN_V;
         for (u32 j = 0; j < ncand; j += 64 * V) {
             int k[V]; double r[V]; bool want[V]; int ds[V], de[V];
 #pragma unroll

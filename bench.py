@@ -10,15 +10,25 @@ Default workload = the configuration BASELINE.json's metric and targets are quot
 MAG-Scholar-C-shape synthetic power-law CSR (12.4 M nodes / 173 M edges + self-loops),
 ppr order 10 alpha 0.2 rmax 1e-5 top-k 32 (scripts/run_mag.sh:7 of the reference).
 
+`python bench.py --gpus N` with no WORLD_SIZE in the environment LAUNCHES the N ranks itself
+(one child process per GPU, rendezvous on 127.0.0.1) before anything in this process touches
+HIP; under `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  N = 1 runs the
+same rank code in-process.
+
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement), carrying
 `roofline` (HBM, algorithmic bytes of SURVEY.md 8d / kernel time from HIP events on the
-launch stream) and, at N = 1, `cpu_baseline` (the CPU checker timed on this box's cores).
+launch stream), `issue_bound` (edge inserts per clock and CU against the measured LDS-atomic
+insert rate), `host_api` (the metric's own clock: host buffers in -> host buffers out through
+gp_gfpush, N = 1) and, at N = 1, `cpu_baseline` (the CPU checker timed on this box's cores).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +39,11 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHADER_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md: max clock (the chip holds less under load: the fraction below is a lower bound)
+N_CUS = 256
+# tools/micro/lds_random.hip on MI355X (profiles/r02_lds_random.txt): one residue-table insert = LDS compare-and-swap
+# + ds_add_f64 on random slots, 16 waves per CU -> 38.2 clk per 64-lane wave-insert = 1.675 edge inserts / clk / CU
+LDS_INSERT_PEAK = 64.0 / 38.2
 
 WORKLOADS = {
     # name: (graph source, recipe key, description)
@@ -39,6 +54,14 @@ WORKLOADS = {
     "cora": ("golden:cora", ("cora", "ppr"), "Cora graph fixture 2.7k nodes / 10.6k edges (+I), ppr order 20 alpha 0.2 rmax 1e-7 K 32, seeds cycled"),
     "small": ("synth:small", ("mag", "ppr"), "100k-node synthetic power-law CSR, MAG recipe (debug)"),
 }
+
+
+def kernel_source_sha16() -> str:
+    """Identity of the GFPush kernel sources: profiles/*_pmc_summary.json carries the hash it was measured on."""
+    h = hashlib.sha256()
+    for f in ("grand_plus_amd/csrc/gfpush_kernels.hpp", "grand_plus_amd/csrc/gfpush.hip"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_graph(source: str, threads: int):
@@ -61,43 +84,72 @@ def make_seeds(source: str, n_nodes: int, total: int):
 
 
 def cpu_baseline(indptr, indices, seeds, recipe, budget_s: float = 12.0):
-    """Time the CPU checker on a bounded sample of the same workload (rank 0, N = 1 only)."""
+    """Time the CPU checker on a bounded sample of the same workload (rank 0, N = 1 only): the reference itself
+    (oracle/_ref, 40 OpenMP threads as shipped, graph.h:41) when it was built, and this repo's restatement at
+    40 threads and on all cores; best of 3 each, on >= 16 384 seeds when the budget allows."""
     from oracle import pyoracle
     coef = recipe.coef()
     cores = os.cpu_count() or 1
-    out = {}
-    # size the sample from a small probe so that the timed part is ~budget_s
-    probe = seeds[:min(len(seeds), 256)]
+    K = recipe.top_k
+    probe = seeds[:min(len(seeds), 512)]
     t = time.perf_counter()
-    pyoracle.gfpush(indptr, indices, probe, coef, recipe.rmax, recipe.top_k, threads=cores)
+    pyoracle.gfpush(indptr, indices, probe, coef, recipe.rmax, K, threads=min(40, cores))
     rate = len(probe) / max(time.perf_counter() - t, 1e-6)
-    n = int(min(len(seeds), max(256, rate * budget_s)))
+    n = int(min(len(seeds), max(16384 if rate * budget_s / 3 >= 16384 else 512, rate * budget_s / 3)))
     sample = seeds[:n]
-    best = 0.0
-    for _ in range(2):
-        t = time.perf_counter()
-        pyoracle.gfpush(indptr, indices, sample, coef, recipe.rmax, recipe.top_k, threads=cores)
-        best = max(best, n / (time.perf_counter() - t))
-    out = {"value": round(best, 1), "unit": "rows/s", "cores": cores, "kind": "port",
-           "sample": f"{n} seeds of the same workload, oracle/gfpush_oracle.cpp (unordered_map + OpenMP dynamic), {cores} threads, best of 2"}
+
+    def best_of(fn, reps=3):
+        best = 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            best = max(best, n / (time.perf_counter() - t0))
+        return round(best, 1)
+
+    port40 = best_of(lambda: pyoracle.gfpush(indptr, indices, sample, coef, recipe.rmax, K, threads=min(40, cores)))
+    port_all = best_of(lambda: pyoracle.gfpush(indptr, indices, sample, coef, recipe.rmax, K, threads=cores)) if cores > 40 else port40
+    out = {"value": port40, "unit": "rows/s", "cores": min(40, cores), "host_cores": cores, "kind": "port",
+           "sample": f"{n} seeds of the same workload, oracle/gfpush_oracle.cpp (unordered_map + OpenMP dynamic), {min(40, cores)} threads, best of 3",
+           "port_40_threads": port40, "port_all_cores": port_all, "port_all_cores_threads": cores}
     ref = pyoracle.load_reference_module()
     if ref is not None:
-        # the reference itself (compiled from its own sources into oracle/_ref); 40 threads hard-coded (graph.h:41)
         g = ref.Graph(indptr, indices, 0)
-        K = recipe.top_k
         row = np.zeros(n * K, np.int32); col = np.zeros(n * K, np.int32); val = np.zeros(n * K, np.float64)
-        rbest = 0.0
-        for _ in range(2):
-            t = time.perf_counter()
-            g.gfpush_omp(sample, row, col, val, coef, recipe.rmax, K)
-            rbest = max(rbest, n / (time.perf_counter() - t))
-        out = {"value": round(rbest, 1), "unit": "rows/s", "cores": 40, "host_cores": cores, "kind": "reference",
-               "sample": f"{n} seeds of the same workload, reference precompute/propagation.cpp compiled as oracle/_ref, 40 OpenMP threads as shipped (graph.h:41) on {cores} cores, best of 2",
-               "port_value": round(best, 1), "port_cores": cores}
+        refv = best_of(lambda: g.gfpush_omp(sample, row, col, val, coef, recipe.rmax, K))
+        out.update({"value": refv, "cores": 40, "kind": "reference",
+                    "sample": f"{n} seeds of the same workload, reference precompute/propagation.cpp compiled as oracle/_ref, 40 OpenMP threads as shipped (graph.h:41) on {cores} cores, best of 3"})
     return out
 
 
-def main():
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int) -> int:
+    """`--gpus N` without a launcher: start N rank processes (this file, one per GPU) and wait.  Runs before this
+    process imports torch or touches HIP, and it never replaces itself with another program."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "WORLD_SIZE": str(n)})
+    print(f"[bench] launching {n} ranks (one process per GPU, rendezvous 127.0.0.1:{env['MASTER_PORT']})", file=sys.stderr, flush=True)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    for r, p in enumerate(procs):
+        code = p.wait()
+        if code != 0:
+            print(f"[bench] rank {r} exited with code {code}", file=sys.stderr, flush=True)
+            rc = rc or code
+    return rc
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -105,13 +157,16 @@ def main():
     ap.add_argument("--workload", default="mag", choices=sorted(WORKLOADS))
     ap.add_argument("--seeds-per-gpu", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--no-host-api", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--force-global", type=int, default=0)
     ap.add_argument("--diag-flags", type=int, default=0, help="GRANDPLUS_DIAG=1 builds only: bit 0 skips TOP-K (instruction attribution)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def run_rank(args) -> int:
     import torch
     import torch.distributed as dist
     from grand_plus_amd import Graph, RECIPES, algorithmic_bytes
@@ -125,16 +180,17 @@ def main():
     # RCCL ("nccl") is the product path.  GRANDPLUS_BENCH_BACKEND=gloo is a debugging aid for boxes with a
     # single GPU (RCCL refuses two ranks on one device): same orchestration, the gather is staged through the host.
     backend = os.environ.get("GRANDPLUS_BENCH_BACKEND", "nccl")
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            rccl_ranks = dist.get_world_size()
         else:
             dist.init_process_group(backend)
+            rccl_ranks = 0
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     source, rkey, desc = WORKLOADS[args.workload]
     recipe = RECIPES[rkey]
@@ -146,8 +202,16 @@ def main():
     n_nodes = len(indptr) - 1
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    graph = Graph(indptr, indices, 0, device=local_rank)
+    try:
+        graph = Graph(indptr, indices, 0, device=local_rank)        # no GPU => GP_ERR_NO_DEVICE (there is no CPU path)
+    except RuntimeError as e:
+        print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 3
     t_upload = time.perf_counter() - t0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if args.block_threads:
         graph.set_option("block_threads", args.block_threads)
     if args.lds_bytes:
@@ -209,32 +273,48 @@ def main():
             gather_rows()
     fence()
     elapsed = time.perf_counter() - t_start
+    stats = graph.stats()                       # counters of the timed steps on this rank; raises if a row failed
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    per_rank_ms = [round(avg_ms, 3)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        red_dev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        km = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        km[rank] = avg_ms
+        dist.all_reduce(km, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x), 3) for x in km.tolist()]
 
-    stats = graph.stats()                       # counters of the timed steps on this rank
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
     if rank == 0:
         rows_total = S_step * args.steps
         value = rows_total / elapsed
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
         bytes_per_launch = algorithmic_bytes(stats) / args.steps
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        edges_per_launch = stats["edges"] / args.steps
+        edges_per_clk_cu = edges_per_launch / (avg_ms * 1e-3) / SHADER_CLOCK_HZ / N_CUS
+        sha = kernel_source_sha16()
         line = {
             "metric": "propagation-matrix rows/sec (whole node)", "value": round(value, 1), "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if source.startswith("synth:") else "fixture graph (tests/golden), seeds cycled",
+            "rccl_ranks": rccl_ranks, "kernel_ms_per_rank": per_rank_ms,
             "config": {"workload": desc, "recipe": f"{recipe.prop_mode} order {recipe.order} alpha {recipe.alpha} rmax {recipe.rmax} K {K}",
                        "seeds_per_gpu": per, "rows_per_step": S_step, "n_nodes": n_nodes, "nnz": int(len(indices)),
                        "sharding": "seeds block-partitioned, CSR replicated" + (", 1 RCCL all-gather of packed rows per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "gfpush_kernel", "kernel_ms_avg": round(avg_ms, 3),
+                         "kernel": "gfpush_kernel", "kernel_ms_avg": round(avg_ms, 3), "kernel_sha16": sha,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "bytes_per_row": round(bytes_per_launch / per, 1)},
+            # the path is not HBM-bound: second yardstick = residue-table inserts per clock and CU against the
+            # LDS-atomic insert rate measured by tools/micro/lds_random.hip (clock taken at its 2.4 GHz maximum)
+            "issue_bound": {"bound": "lds_atomic_insert", "achieved": round(edges_per_clk_cu, 5), "peak": round(LDS_INSERT_PEAK, 3),
+                            "unit": "edges/clk/CU", "frac": round(edges_per_clk_cu / LDS_INSERT_PEAK, 5),
+                            "clock_hz": SHADER_CLOCK_HZ, "source": "tools/micro/lds_random.hip -> profiles/r02_lds_random.txt"},
             "detail": {"pushes_per_row": round(stats["pushes"] / stats["rows"], 1),
                        "edges_per_row": round(stats["edges"] / stats["rows"], 1),
                        "support_per_row": round(stats["support"] / stats["rows"], 1),
@@ -246,13 +326,17 @@ def main():
                        "lds_bytes": stats["lds_bytes"], "workspace_gb": round(stats["workspace_bytes"] / 2**30, 2),
                        "graph_gen_s": round(t_gen, 2), "csr_upload_s": round(t_upload, 3)},
         }
-        # HBM-side traffic per launch: measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes of
-        # this same command) and committed under profiles/; a bench run cannot profile itself.
+        # HBM-side traffic per launch: measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes of this
+        # same command, tools/collect_pmc.sh) and committed under profiles/ together with the hash of the kernel
+        # sources it was measured on; a bench run cannot profile itself, and a profile of OTHER sources is not reported.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_mag_pmc_summary.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_mag_pmc_summary.json")))
             if args.workload == prof.get("workload") and per == prof.get("seeds_per_gpu") and world == 1:
-                line["roofline"]["traffic"] = int(prof["derived"]["hbm_read_bytes_raw"] + prof["derived"]["hbm_write_bytes"])
-                line["roofline"]["traffic_source"] = "profiles/r01_mag_pmc_summary.json (rocprofv3 FETCH_SIZE+WRITE_SIZE, raw; see note there)"
+                if prof.get("kernel_sha16") == sha:
+                    line["roofline"]["traffic"] = int(prof["derived"]["hbm_read_bytes_raw"] + prof["derived"]["hbm_write_bytes"])
+                    line["roofline"]["traffic_source"] = "profiles/r02_mag_pmc_summary.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, raw counters, same kernel sources; see the note there about the gfx950 read counter)"
+                else:
+                    line["roofline"]["traffic_source"] = f"none: profiles/r02_mag_pmc_summary.json was measured on kernel sources {prof.get('kernel_sha16')}, this run is {sha}"
         except (OSError, KeyError, ValueError):
             pass
         if stats.get("diag_ticks_total"):
@@ -261,6 +345,20 @@ def main():
             names = ["agg_init", "agg_insert", "agg_scan", "sel_hist", "sel_pick", "sel_compact", "sel_collect", "final"]
             line["detail"]["diag_topk_sub_share"] = {n: round(stats["diag_sub"][i] / tot, 3) for i, n in enumerate(names)}
             line["detail"]["diag_counts_per_row"] = {"agg_parts": round(stats["diag_sub"][8] / stats["rows"], 2), "sel_passes_hbm": round(stats["diag_sub"][9] / stats["rows"], 2), "sel_passes_lds": round(stats["diag_sub"][10] / stats["rows"], 2)}
+        if world == 1 and not args.no_host_api:
+            # The metric's own clock: the gfpush_omp call, host buffers in -> host buffers out
+            # (model.py:268), through gp_gfpush: seed upload, kernel, one packed D2H, scatter of the v > 0 slots.
+            hs = all_seeds[args.warmup * S_step:args.warmup * S_step + per].astype(np.int64)
+            row = np.zeros(per * K, np.int32); col = np.zeros(per * K, np.int32); val = np.zeros(per * K, np.float64)
+            ts = []
+            for _ in range(4):
+                t1 = time.perf_counter()
+                graph.gfpush_omp(hs, row, col, val, coef, recipe.rmax, K)
+                ts.append(time.perf_counter() - t1)
+            med = sorted(ts[1:])[1]
+            line["host_api"] = {"rows_per_s": round(per / med, 1), "ms_per_call": round(med * 1e3, 3), "rows_per_call": per,
+                                "first_call_ms": round(ts[0] * 1e3, 3),
+                                "what": "Graph.gfpush_omp (gp_gfpush): int64 seeds on the host -> numpy row/col/value filled in place, median of 3 calls after one warm-up"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(indptr, indices, all_seeds[args.warmup * S_step:], recipe, args.cpu_budget_s)
             line["cpu_baseline"] = cb
@@ -269,6 +367,14 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -71,10 +71,10 @@ struct gp_graph {
     bool reset_pending = true; int64_t rows_total = 0;
     gp_stats last{};
     // staging for the host-buffer entry point
+    // one packed slab [val f64 x slots | row i32 x slots | col i32 x slots | filled i32 x seeds] on the device and one pinned
+    // mirror: the rows come back with ONE D2H copy (the layout grand_plus_amd/sharded.py all-gathers)
     int* d_seeds = nullptr; int64_t seeds_cap = 0;
-    int *d_row = nullptr, *d_col = nullptr, *d_filled = nullptr; double* d_val = nullptr; int64_t out_cap = 0;
-    int *h_row = nullptr, *h_col = nullptr, *h_filled = nullptr; double* h_val = nullptr; int64_t hout_cap = 0;
-    int64_t hfilled_cap = 0, dfilled_cap = 0;
+    char* d_out = nullptr; char* h_out = nullptr; size_t out_bytes = 0;
 };
 
 namespace {
@@ -296,14 +296,8 @@ void gp_graph_destroy(gp_graph* g) {
     if (g->h_counters) (void)hipHostFree(g->h_counters);
     if (g->d_coef) (void)hipFree(g->d_coef);
     if (g->d_seeds) (void)hipFree(g->d_seeds);
-    if (g->d_row) (void)hipFree(g->d_row);
-    if (g->d_col) (void)hipFree(g->d_col);
-    if (g->d_val) (void)hipFree(g->d_val);
-    if (g->d_filled) (void)hipFree(g->d_filled);
-    if (g->h_row) (void)hipHostFree(g->h_row);
-    if (g->h_col) (void)hipHostFree(g->h_col);
-    if (g->h_val) (void)hipHostFree(g->h_val);
-    if (g->h_filled) (void)hipHostFree(g->h_filled);
+    if (g->d_out) (void)hipFree(g->d_out);
+    if (g->h_out) (void)hipHostFree(g->h_out);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -535,40 +529,30 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
     const int64_t slots = n_seeds * (int64_t)K;
     if (n_seeds > g->seeds_cap) {
         if (g->d_seeds) (void)hipFree(g->d_seeds);
-        if (g->d_filled) (void)hipFree(g->d_filled);
-        if (g->h_filled) (void)hipHostFree(g->h_filled);
-        g->d_seeds = nullptr; g->d_filled = nullptr; g->h_filled = nullptr; g->seeds_cap = 0;
+        g->d_seeds = nullptr; g->seeds_cap = 0;
         HIP_TRY(hipMalloc(&g->d_seeds, sizeof(int) * (size_t)n_seeds));
-        HIP_TRY(hipMalloc(&g->d_filled, sizeof(int) * (size_t)n_seeds));
-        HIP_TRY(hipHostMalloc(&g->h_filled, sizeof(int) * (size_t)n_seeds));
         g->seeds_cap = n_seeds;
     }
-    if (slots > g->out_cap) {
-        if (g->d_row) (void)hipFree(g->d_row);
-        if (g->d_col) (void)hipFree(g->d_col);
-        if (g->d_val) (void)hipFree(g->d_val);
-        if (g->h_row) (void)hipHostFree(g->h_row);
-        if (g->h_col) (void)hipHostFree(g->h_col);
-        if (g->h_val) (void)hipHostFree(g->h_val);
-        g->d_row = g->d_col = nullptr; g->d_val = nullptr; g->h_row = g->h_col = nullptr; g->h_val = nullptr;
-        g->out_cap = 0;
-        HIP_TRY(hipMalloc(&g->d_row, sizeof(int) * (size_t)slots));
-        HIP_TRY(hipMalloc(&g->d_col, sizeof(int) * (size_t)slots));
-        HIP_TRY(hipMalloc(&g->d_val, sizeof(double) * (size_t)slots));
-        HIP_TRY(hipHostMalloc(&g->h_row, sizeof(int) * (size_t)slots));
-        HIP_TRY(hipHostMalloc(&g->h_col, sizeof(int) * (size_t)slots));
-        HIP_TRY(hipHostMalloc(&g->h_val, sizeof(double) * (size_t)slots));
-        g->out_cap = slots;
+    const size_t off_row = 8 * (size_t)slots, off_col = 12 * (size_t)slots, off_filled = 16 * (size_t)slots;
+    const size_t need_bytes = off_filled + 4 * (size_t)n_seeds;
+    if (need_bytes > g->out_bytes) {
+        if (g->d_out) (void)hipFree(g->d_out);
+        if (g->h_out) (void)hipHostFree(g->h_out);
+        g->d_out = nullptr; g->h_out = nullptr; g->out_bytes = 0;
+        HIP_TRY(hipMalloc(&g->d_out, need_bytes));
+        HIP_TRY(hipHostMalloc(&g->h_out, need_bytes));
+        g->out_bytes = need_bytes;
     }
+    double* d_val = (double*)g->d_out; int* d_row = (int*)(g->d_out + off_row); int* d_col = (int*)(g->d_out + off_col);
+    int* d_filled = (int*)(g->d_out + off_filled);
+    const double* h_val = (const double*)g->h_out; const int* h_row = (const int*)(g->h_out + off_row);
+    const int* h_col = (const int*)(g->h_out + off_col); const int* h_filled = (const int*)(g->h_out + off_filled);
     hipStream_t s = g->stream;
     g->reset_pending = true;                   // the host-buffer call reports its own counters
     HIP_TRY(hipMemcpyAsync(g->d_seeds, seeds, sizeof(int) * (size_t)n_seeds, hipMemcpyHostToDevice, s));
-    rc = gp_gfpush_device(g, g->d_seeds, n_seeds, coef, n_coef, rmax, K, g->d_row, g->d_col, g->d_val, g->d_filled, s);
+    rc = gp_gfpush_device(g, g->d_seeds, n_seeds, coef, n_coef, rmax, K, d_row, d_col, d_val, d_filled, s);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(g->h_filled, g->d_filled, sizeof(int) * (size_t)n_seeds, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(g->h_row, g->d_row, sizeof(int) * (size_t)slots, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(g->h_col, g->d_col, sizeof(int) * (size_t)slots, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(g->h_val, g->d_val, sizeof(double) * (size_t)slots, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(g->h_out, g->d_out, need_bytes, hipMemcpyDeviceToHost, s));      // one packed copy
     rc = gp_get_stats(g, nullptr);             // synchronises the stream
     if (rc) return rc;
     // Write only the filled (v > 0) slots: everything else keeps the caller's contents (graph.h:121).
@@ -578,11 +562,11 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
     auto scatter = [&](int64_t lo, int64_t hi) {
         for (int64_t it = lo; it < hi; ++it) {
             const int64_t o = it * (int64_t)K;
-            const int nf = g->h_filled[it];
+            const int nf = h_filled[it];
             if (nf <= 0) continue;
-            std::memcpy(row_idx + o, g->h_row + o, sizeof(int) * (size_t)nf);
-            std::memcpy(col_idx + o, g->h_col + o, sizeof(int) * (size_t)nf);
-            std::memcpy(value + o, g->h_val + o, sizeof(double) * (size_t)nf);
+            std::memcpy(row_idx + o, h_row + o, sizeof(int) * (size_t)nf);
+            std::memcpy(col_idx + o, h_col + o, sizeof(int) * (size_t)nf);
+            std::memcpy(value + o, h_val + o, sizeof(double) * (size_t)nf);
         }
     };
     const int n_thr = slots >= (int64_t)(4 << 20) ? 8 : 1;

@@ -94,7 +94,7 @@ def test_make_coef_follows_reference_recipe():
     np.testing.assert_array_equal(make_coef("avg", 4), np.full(5, 0.2))
     np.testing.assert_array_equal(make_coef("single", 2), np.array([0.0, 0.0, 1.0]))
     with pytest.raises(ValueError, match="Unknown propagation mode"):
-        make_coef("heat", 2)
+        make_coef("bogus", 2)
     ip, ix = add_self_loops_csr(np.array([0, 1, 1, 2], np.int32), np.array([1, 2], np.int32))
     assert ip.tolist() == [0, 2, 3, 4] and ix.tolist() == [0, 1, 1, 2]   # node 2 already had its loop
 
@@ -142,3 +142,29 @@ def test_synth_seeds_are_a_permutation_prefix():
     s = synth.seeds(1000, 1000)
     assert sorted(s.tolist()) == list(range(1000))
     np.testing.assert_array_equal(synth.seeds(1000, 10), s[:10])
+
+
+def test_bench_gpus_flag_launches_one_process_per_gpu():
+    """`bench.py --gpus 2` without a launcher starts two ranks itself (the driver's SCALE call).
+    Here there is no GPU: both ranks must come up, rendezvous (gloo) and stop at GP_ERR_NO_DEVICE -- there is
+    no CPU path to fall back to -- and the launcher must report the failure through its exit code."""
+    import subprocess
+    import sys
+    if not _no_gpu():
+        pytest.skip("needs a GPU-less box")
+    env = dict(os.environ, GRANDPLUS_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--workload", "small", "--seeds-per-gpu", "64"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "launching 2 ranks" in r.stderr
+    assert "rank 0:" in r.stderr and "rank 1:" in r.stderr
+    assert r.stderr.count("no HIP device") + r.stderr.count("no CPU path") >= 2
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no JSON line from a run that measured nothing
+
+
+def test_bench_kernel_hash_is_stable_and_traffic_is_tied_to_it():
+    import bench
+    sha = bench.kernel_source_sha16()
+    assert re.fullmatch(r"[0-9a-f]{16}", sha) and sha == bench.kernel_source_sha16()

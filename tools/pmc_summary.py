@@ -35,9 +35,14 @@ if g("SQ_WAVE_CYCLES"):
     if g("SQ_WAIT_ANY"): d["wave_wait_fraction"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
     if g("SQ_ACTIVE_INST_ANY"): d["wave_active_fraction"] = g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")
 if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE"): d["lds_bank_conflict_fraction"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
-json.dump({"workload": a.workload, "seeds_per_gpu": a.rows,
+import hashlib, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in ("grand_plus_amd/csrc/gfpush_kernels.hpp", "grand_plus_amd/csrc/gfpush.hip"):
+    _h.update(open(os.path.join(ROOT, _f), "rb").read())
+json.dump({"workload": a.workload, "seeds_per_gpu": a.rows, "kernel_sha16": _h.hexdigest()[:16],
            "command": "tools/collect_pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline (one pass per group; mean of the 5 timed launches)",
-           "kernel": "gp::gfpush_kernel<1024>", "per_launch": per, "derived": d,
+           "kernel": "gp::gfpush_kernel", "per_launch": per, "derived": d,
            "note": "FETCH_SIZE = TCC_EA0_RDREQ x 64 B / 1024. MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly 1/2 of a 16-B/lane coalesced stream; this kernel issues 4-12 B/lane accesses (uncalibrated), so the true read volume lies between 1x and 2x of hbm_read_bytes_raw. Infinity-Cache hits are included."},
           open(a.out, "w"), indent=1)
 print(json.dumps(d, indent=1))

@@ -324,6 +324,8 @@ def run_rank(args) -> int:
                        "lds_levels": stats["lds_levels"], "global_levels": stats["global_levels"],
                        "workgroups": stats["workgroups"], "block_threads": stats["block_threads"],
                        "lds_bytes": stats["lds_bytes"], "workspace_gb": round(stats["workspace_bytes"] / 2**30, 2),
+                       "retried_rows": stats["retried_rows"], "max_level_edges": stats["max_level_edges"],
+                       "max_log_records": stats["max_log_records"],
                        "graph_gen_s": round(t_gen, 2), "csr_upload_s": round(t_upload, 3)},
         }
         # HBM-side traffic per launch: measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes of this

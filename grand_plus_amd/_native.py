@@ -43,6 +43,7 @@ class GpStats(ctypes.Structure):
         ("diag_ticks_topk", ctypes.c_int64), ("diag_ticks_total", ctypes.c_int64),
         ("diag_ticks_scan_hbm", ctypes.c_int64), ("diag_ticks_expand_hbm", ctypes.c_int64),
         ("diag_sub", ctypes.c_int64 * 16),
+        ("retried_rows", ctypes.c_int64), ("max_level_edges", ctypes.c_int64), ("max_log_records", ctypes.c_int64),
     ]
 
     def as_dict(self):
@@ -113,7 +114,7 @@ def lib():
     L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
-    if L.gp_abi_version() != 1:
+    if L.gp_abi_version() != 2:
         raise RuntimeError("libgrandplus.so ABI version mismatch")
     _LIB = L
     return L

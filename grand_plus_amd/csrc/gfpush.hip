@@ -40,12 +40,35 @@ int fail(int status, const char* fmt, ...) {
                         #expr, hipGetErrorString(e_));                                      \
     } while (0)
 
-struct Workspace {
-    void* base = nullptr; size_t bytes = 0;
+// One set of per-workgroup scratch slabs (all caps are per workgroup).
+struct Slabs {
     int n_wg = 0;
     u64 push_cap = 0, resg_cap = 0, log_cap = 0, cand_cap = 0, bucket_cap = 0;
     PushEntry* push = nullptr; ResRec* resg = nullptr; ResRec* bucket = nullptr;
     int* log_key = nullptr; double* log_val = nullptr; Cand* cand = nullptr;
+    size_t per_wg() const { return 16 * (size_t)(2 * push_cap + resg_cap + cand_cap + bucket_cap) + 12 * (size_t)log_cap + 64; }
+    size_t carve(char* p, int wgs) {                                   // lays the arrays out at p, returns the bytes used
+        n_wg = wgs;
+        char* q = p;
+        push = (PushEntry*)q;  q += 16 * (size_t)wgs * 2 * push_cap;
+        resg = (ResRec*)q;     q += 16 * (size_t)wgs * resg_cap;
+        cand = (Cand*)q;       q += 16 * (size_t)wgs * cand_cap;
+        bucket = (ResRec*)q;   q += 16 * (size_t)wgs * bucket_cap;
+        log_val = (double*)q;  q += 8 * (size_t)wgs * log_cap;
+        log_key = (int*)q;     q += 4 * (size_t)wgs * log_cap;
+        return ((size_t)(q - p) + 255) & ~(size_t)255;
+    }
+    bool covers(const Slabs& o) const {
+        return n_wg >= o.n_wg && push_cap >= o.push_cap && resg_cap >= o.resg_cap && log_cap >= o.log_cap &&
+               cand_cap >= o.cand_cap && bucket_cap >= o.bucket_cap;
+    }
+};
+
+struct Workspace {
+    void* base = nullptr; size_t bytes = 0;
+    Slabs est;                    // first launch: every workgroup, slabs sized from an estimate of a row's needs
+    Slabs big;                    // retry launch: a few workgroups, slabs sized from the rigorous bounds (n_wg == 0: not needed)
+    uint32_t* retry_list = nullptr; int64_t retry_cap = 0;
     bool dirty = true;            // HBM residue tables need (re)initialising before the next launch
 };
 
@@ -61,6 +84,9 @@ struct gp_graph {
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1;
+    int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
+    double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
+    double est_rmax = -1.0; int est_n_coef = 0;                            // the call parameters that estimate belongs to
     // per-call state
     Workspace ws;
     u64* d_counters = nullptr; u64* h_counters = nullptr;      // pinned host mirror
@@ -101,54 +127,98 @@ void free_workspace(Workspace& w) {
     w = Workspace();
 }
 
-// Per-workgroup bounds.  The residue mass of a level never exceeds 1.0 (up to fp64 rounding)
-// and a pushed node has deg <= r/rmax, so the degrees pushed in one level sum to <= 1/rmax;
-// the 0.1 % + 16 slack covers the rounding.  A row that still exceeds a bound is reported
-// (GP_ERR_OVERFLOW), never silently truncated.
+// Per-workgroup slab sizes for levels of up to `e_max` edges each (and `log_records` reserve-log records per row; 0 =
+// the bound that follows from e_max).  With e_max = the rigorous bound this is the worst case:
+// the residue mass of a level never exceeds 1.0 (up to fp64 rounding) and a pushed node has deg <= r/rmax, so the degrees
+// pushed in one level sum to <= 1/rmax; the 0.1 % + 16 slack covers the rounding.
 //   E_max  = edges traversed in one level  <= min(nnz, 1.001/rmax + 16)
 //   F_max  = frontier size of one level    <= min(N, E_max) + 1          (+1: dangling -> seed)
 //   reserve-log records of a row           <= (L+1) * F_max
 //   support of the reserve map             <= min(N, 1 + L*F_max)
-int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg_wanted) {
-    const double nnz_d = (double)g->nnz, n_d = (double)g->n_nodes;
-    double e_max = nnz_d;
-    if (rmax > 0.0) e_max = std::min(nnz_d, std::floor(1.001 / rmax) + 16.0);
+Slabs slab_sizes(const gp_graph* g, int n_coef, double e_max, double log_records) {
+    const double n_d = (double)g->n_nodes;
     const double f_max = std::min(n_d, e_max) + 1.0;
     const double L = (double)(n_coef - 1);
-    const double supp = std::max(1.0, std::min(n_d, 1.0 + L * f_max));
-    const double logn = (L + 1.0) * f_max + 64.0;
-    if (2.0 * f_max > 4.0e9 || logn > 4.0e9)
-        return fail(GP_ERR_INVALID_ARG, "workspace bound exceeds 32-bit record space (order %d, rmax %g)", n_coef - 1, rmax);
-    const u64 resg_cap = (u64)std::max(2048.0, 2.0 * f_max);
-    const u64 log_cap = (u64)logn;
-    const u64 cand_cap = (u64)supp + 1;
-    const u64 push_cap = (u64)(f_max + e_max / kSplitLen + 2.0);
-    const u64 bucket_cap = (u64)e_max + 2;                 // (key, share) records of one bucketed level
-    const size_t per_wg = 16 * (size_t)(2 * push_cap + resg_cap + cand_cap + bucket_cap) + 12 * (size_t)log_cap + 64;
-    const size_t budget = (size_t)g->workspace_mb << 20;
-    int n_wg = n_wg_wanted;
-    if ((size_t)n_wg * per_wg > budget) n_wg = (int)std::max<size_t>(1, budget / per_wg);
+    double logn = (L + 1.0) * f_max + 64.0;
+    if (log_records > 0.0) logn = std::min(logn, log_records + 64.0);
+    const double supp = std::max(1.0, std::min(std::min(n_d, 1.0 + L * f_max), logn));
+    Slabs sl;
+    sl.resg_cap = (u64)std::max(2048.0, 2.0 * f_max);
+    sl.log_cap = ((u64)logn + 3) & ~3ull;
+    sl.cand_cap = (u64)supp + 1;
+    sl.push_cap = (u64)(f_max + e_max / kSplitLen + 2.0);
+    sl.bucket_cap = (u64)e_max + 2;                 // (key, share) records of one bucketed level
+    return sl;
+}
+
+double level_edge_bound(const gp_graph* g, double rmax) {
+    double e = (double)g->nnz;
+    if (rmax > 0.0) e = std::min(e, std::floor(1.001 / rmax) + 16.0);
+    return e;
+}
+
+// Workspace policy.  Sizing every workgroup's slab from the 1/rmax bound does not scale: the Cora recipe's
+// rmax 1e-7 on a large graph asks for ~2 GB per workgroup, and a fixed budget then silently cut the launch to a few dozen
+// workgroups.  Now ALL resident workgroups get a slab sized for what rows of this graph and recipe actually need -- an
+// estimate that starts at max(32 Ki edges per level, bound / 4), is capped so that the slabs fit HALF the budget, and grows
+// from the maxima the kernel observes -- and a handful of workgroups of a second launch hold bound-sized slabs for the rows
+// that outgrow the estimate (they are detected exactly as before and moved to a retry list instead of failing).
+int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_seeds) {
+    const double bound = level_edge_bound(g, rmax);
+    {
+        const Slabs worst = slab_sizes(g, n_coef, bound, 0.0);
+        if (2.0 * (double)worst.resg_cap > 8.0e9 || (double)worst.log_cap > 4.0e9)
+            return fail(GP_ERR_INVALID_ARG, "workspace bound exceeds 32-bit record space (order %d, rmax %g)", n_coef - 1, rmax);
+    }
+    size_t budget = (size_t)g->workspace_mb << 20;
+    {   // never plan beyond what the device can give right now: our own cached workspace counts as free
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)(0.9 * (double)(free_b + g->ws.bytes)));
+        else (void)hipGetLastError();
+    }
+    if (g->est_rmax != rmax || g->est_n_coef != n_coef) {            // a new recipe: forget the running estimate
+        g->est_rmax = rmax; g->est_n_coef = n_coef; g->est_edges = 0.0; g->est_log = 0.0;
+    }
+    double e_est = g->est_level_edges > 0 ? (double)g->est_level_edges
+                                          : std::max(g->est_edges, std::max(32768.0, bound / 4.0));
+    e_est = std::min(e_est, bound);
+    double log_est = e_est >= bound ? 0.0 : std::max(g->est_log, 4.0 * e_est);
+    Slabs est = slab_sizes(g, n_coef, e_est, log_est);
+    while ((double)est.per_wg() * n_wg > 0.5 * (double)budget && e_est > 4096.0) {     // shrink the slabs, not the launch
+        e_est *= 0.75; log_est = std::max(4096.0, 0.75 * (log_est > 0.0 ? log_est : (double)est.log_cap));
+        est = slab_sizes(g, n_coef, e_est, log_est);
+    }
+    if ((double)est.per_wg() * n_wg > 0.5 * (double)budget) n_wg = (int)std::max<size_t>(1, budget / 2 / est.per_wg());
+    est.n_wg = n_wg;
+    Slabs big;                                                       // needed only if the estimate is below the bound
+    if (e_est < bound || log_est > 0.0) {
+        big = slab_sizes(g, n_coef, bound, 0.0);
+        const size_t left = budget - std::min(budget, est.per_wg() * (size_t)n_wg);
+        int nb = (int)std::min<size_t>(8, left / std::max<size_t>(1, big.per_wg()));
+        if (nb < 1) {                                                // not even one worst-case slab fits: give it what is left
+            double e_big = bound;
+            while (e_big > e_est && slab_sizes(g, n_coef, e_big, 0.0).per_wg() > left) e_big *= 0.8;
+            big = slab_sizes(g, n_coef, std::max(e_big, e_est), 0.0);
+            nb = 1;
+        }
+        big.n_wg = std::min(nb, n_wg);
+    }
 
     Workspace& w = g->ws;
-    const bool fits = w.base && w.n_wg >= n_wg && w.push_cap >= push_cap && w.resg_cap >= resg_cap &&
-                      w.log_cap >= log_cap && w.cand_cap >= cand_cap && w.bucket_cap >= bucket_cap;
+    const bool fits = w.base && w.est.covers(est) && w.big.covers(big) && w.retry_cap >= n_seeds;
     if (!fits) {
         free_workspace(w);
-        const size_t total = (size_t)n_wg * per_wg + 4096;
+        const size_t total = est.per_wg() * (size_t)est.n_wg + big.per_wg() * (size_t)big.n_wg + 4 * (size_t)std::max<int64_t>(n_seeds, 1) + 4096 + 1024;
         hipError_t e = hipMalloc(&w.base, total);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             return fail(GP_ERR_NOMEM, "hipMalloc(%zu bytes of gfpush workspace): %s", total, hipGetErrorString(e));
         }
-        w.bytes = total; w.n_wg = n_wg;
-        w.push_cap = push_cap; w.resg_cap = resg_cap; w.log_cap = log_cap; w.cand_cap = cand_cap; w.bucket_cap = bucket_cap;
+        w.bytes = total;
         char* p = (char*)w.base;
-        w.push = (PushEntry*)p; p += 16 * (size_t)n_wg * 2 * push_cap;
-        w.resg = (ResRec*)p;    p += 16 * (size_t)n_wg * resg_cap;
-        w.cand = (Cand*)p;      p += 16 * (size_t)n_wg * cand_cap;
-        w.bucket = (ResRec*)p;  p += 16 * (size_t)n_wg * bucket_cap;
-        w.log_val = (double*)p; p += 8 * (size_t)n_wg * log_cap;
-        w.log_key = (int*)p;
+        w.est = est; p += w.est.carve(p, est.n_wg);
+        w.big = big; if (big.n_wg > 0) p += w.big.carve(p, big.n_wg);
+        w.retry_list = (uint32_t*)p; w.retry_cap = std::max<int64_t>(n_seeds, 1);
         w.dirty = true;
     }
     return GP_OK;
@@ -323,6 +393,9 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "workspace_mb") {
         if (value < 1) return fail(GP_ERR_INVALID_ARG, "workspace_mb must be >= 1");
         g->workspace_mb = value;
+    } else if (k == "est_level_edges") {
+        if (value < 0) return fail(GP_ERR_INVALID_ARG, "est_level_edges must be >= 0");
+        g->est_level_edges = value;
     } else if (k == "force_global") {
         g->force_global = value ? 1 : 0;
     } else if (k == "exact_stats") {
@@ -398,17 +471,17 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         n_wg = g->num_cus * per_cu;
         if (g->max_workgroups > 0) n_wg = std::min(n_wg, g->max_workgroups);
         n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(n_wg, n_seeds));
-        rc = ensure_workspace(g, n_coef, rmax, n_wg);
+        rc = ensure_workspace(g, n_coef, rmax, n_wg, n_seeds);
         if (rc) return rc;
         // the workspace budget could not hold two workgroups per CU: one big workgroup per CU is better than
         // a half-empty chip
-        if (two_per_cu && g->ws.n_wg < n_wg && g->ws.n_wg < 2 * g->num_cus) { two_per_cu = false; continue; }
+        if (two_per_cu && g->ws.est.n_wg < n_wg && g->ws.est.n_wg < 2 * g->num_cus) { two_per_cu = false; continue; }
         break;
     }
     rc = ensure_packed(g, s);
     if (rc) return rc;
     Workspace& w = g->ws;
-    n_wg = std::min(n_wg, w.n_wg);
+    n_wg = std::min(n_wg, w.est.n_wg);
 
     if (n_coef > g->coef_cap) {
         if (g->d_coef) (void)hipFree(g->d_coef);
@@ -421,10 +494,12 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * kNumCounters, s));
         g->reset_pending = false; g->rows_total = 0;
     } else {
-        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64), s));          // the row queue head only
+        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * (kRetryRows + 1), s));   // the two queue heads and the retry count
     }
     if (w.dirty) {
-        hipLaunchKernelGGL(init_tables_kernel, dim3(4096), dim3(256), 0, s, w.resg, (u64)w.n_wg * w.resg_cap);
+        hipLaunchKernelGGL(init_tables_kernel, dim3(4096), dim3(256), 0, s, w.est.resg, (u64)w.est.n_wg * w.est.resg_cap);
+        if (w.big.n_wg > 0)
+            hipLaunchKernelGGL(init_tables_kernel, dim3(1024), dim3(256), 0, s, w.big.resg, (u64)w.big.n_wg * w.big.resg_cap);
         HIP_TRY(hipGetLastError());
         w.dirty = false;
     }
@@ -435,11 +510,17 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.seeds = d_seeds; kp.n_seeds = n_seeds;
     kp.coef = g->d_coef; kp.n_coef = n_coef; kp.rmax = rmax; kp.K = K;
     kp.out_row = d_row; kp.out_col = d_col; kp.out_val = d_val; kp.out_filled = d_filled;
-    kp.push = w.push; kp.push_cap = w.push_cap;
-    kp.resg = w.resg; kp.resg_cap = w.resg_cap;
-    kp.log_key = w.log_key; kp.log_val = w.log_val; kp.log_cap = w.log_cap;
-    kp.cand = w.cand; kp.cand_cap = w.cand_cap;
-    kp.bucket = w.bucket; kp.bucket_cap = w.bucket_cap;
+    auto use_slabs = [&kp](const Slabs& sl) {
+        kp.push = sl.push; kp.push_cap = sl.push_cap;
+        kp.resg = sl.resg; kp.resg_cap = sl.resg_cap;
+        kp.log_key = sl.log_key; kp.log_val = sl.log_val; kp.log_cap = sl.log_cap;
+        kp.cand = sl.cand; kp.cand_cap = sl.cand_cap;
+        kp.bucket = sl.bucket; kp.bucket_cap = sl.bucket_cap;
+    };
+    use_slabs(w.est);
+    const bool two_tier = w.big.n_wg > 0;
+    kp.row_map = nullptr; kp.n_rows_dev = nullptr; kp.queue_counter = kQueue;
+    kp.retry_list = two_tier ? w.retry_list : nullptr;
     kp.counters = g->d_counters;
     kp.lds_slots = lds_slots;
     kp.force_global = g->force_global;
@@ -452,15 +533,27 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.direct = (block_threads == 512 && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
 
+    auto launch = [&](int wgs) {
+        switch (block_threads) {
+            case 256: return launch_kernel<256>(kp, wgs, lds_bytes, s);
+            case 512: return launch_kernel<512>(kp, wgs, lds_bytes, s);
+            case 768: return launch_kernel<768>(kp, wgs, lds_bytes, s);
+            default:  return launch_kernel<1024>(kp, wgs, lds_bytes, s);
+        }
+    };
     HIP_TRY(hipEventRecord(g->ev0, s));
     if (n_seeds > 0) {
-        switch (block_threads) {
-            case 256: rc = launch_kernel<256>(kp, n_wg, lds_bytes, s); break;
-            case 512: rc = launch_kernel<512>(kp, n_wg, lds_bytes, s); break;
-            case 768: rc = launch_kernel<768>(kp, n_wg, lds_bytes, s); break;
-            default:  rc = launch_kernel<1024>(kp, n_wg, lds_bytes, s); break;
-        }
+        rc = launch(n_wg);
         if (rc) return rc;
+        if (two_tier) {
+            // Retry launch, enqueued unconditionally (no host synchronisation): it reads the number of rows that outgrew
+            // their slab from device memory and is a few microseconds of nothing when that number is zero.
+            use_slabs(w.big);
+            kp.row_map = w.retry_list; kp.n_rows_dev = g->d_counters + kRetryRows; kp.queue_counter = kQueueRetry;
+            kp.retry_list = nullptr;
+            rc = launch(w.big.n_wg);
+            if (rc) return rc;
+        }
     }
     HIP_TRY(hipEventRecord(g->ev1, s));
     HIP_TRY(hipMemcpyAsync(g->h_counters, g->d_counters, sizeof(u64) * kNumCounters, hipMemcpyDeviceToHost, s));
@@ -498,6 +591,15 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     s.global_levels = (int64_t)g->h_counters[kGlobalLevels];
     s.failed_rows = (int64_t)g->h_counters[kFailedRows];
     s.degree_lookups = (int64_t)g->h_counters[kDegLookups];
+    s.retried_rows = (int64_t)g->h_counters[kRetriedTotal];
+    s.max_level_edges = (int64_t)g->h_counters[kMaxLevelEdges];
+    s.max_log_records = (int64_t)g->h_counters[kMaxLogRecords];
+    // grow the estimate the next call's slabs are sized from: 1.5 x the largest level / log seen so far, and at
+    // least double it when more than 2 % of the rows had to take the retry launch
+    if (g->est_level_edges == 0) {
+        g->est_edges = std::max(g->est_edges, 1.5 * (double)s.max_level_edges);
+        g->est_log = std::max(g->est_log, 1.5 * (double)s.max_log_records);
+    }
     s.diag_ticks_scan = (int64_t)g->h_counters[kTicksScan];
     s.diag_ticks_expand = (int64_t)g->h_counters[kTicksExpand];
     s.diag_ticks_topk = (int64_t)g->h_counters[kTicksTopk];

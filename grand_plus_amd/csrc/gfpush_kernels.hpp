@@ -109,6 +109,7 @@ struct Ctl {
                           // sits in what used to be alignment padding in front of st[]
     u64 st[12];           // statistics of this workgroup (Stat), flushed to p.counters once at the end
     u32 tk_wide;          // top-K: a candidate lies outside [2^-63, 2): the first digit needs the 4096-bin histogram
+    u64 st_row[12];       // statistics of the row in flight: added to st[] when the row completes, dropped when it is handed to the retry launch
 #ifdef GP_DIAG
     u64 barw[16];         // per wave: shader cycles spent waiting at workgroup barriers
     u32 barn[16];         // per wave: barriers passed
@@ -118,7 +119,10 @@ struct Ctl {
 // cost 18 of the 128 VGPRs (spills).  Phases count in function-local registers and one lane per wave
 // adds the wave's totals here when the phase ends.
 enum Stat { sPush = 0, sEdges, sFront, sDeg, sFilled, sSupport, sLds, sGlb, sFailed, sNumStats };
-__device__ __forceinline__ void stat_add(Ctl* ctl, int which, u64 n) {
+__device__ __forceinline__ void stat_add(Ctl* ctl, int which, u64 n) {           // counts for the row in flight
+    __hip_atomic_fetch_add(&ctl->st_row[which], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void stat_add_final(Ctl* ctl, int which, u64 n) {     // counts that do not belong to a row's own work (failed rows)
     __hip_atomic_fetch_add(&ctl->st[which], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // Inclusive prefix sum over the wave with DPP row shifts / broadcasts: 6 adds and no LDS round trip
@@ -136,7 +140,10 @@ __device__ __forceinline__ u32 wave_sum32(u32 x) {           // sum over the wav
     return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63);
 }
 
-enum Counter { kQueue = 0, kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
+enum Counter { kQueue = 0, kQueueRetry, kRetryRows,          // zeroed at every call: row queue heads of the two launches, rows handed to the retry launch
+               kMaxLevelEdges, kMaxLogRecords,                // observed maxima (atomic max): what the next call's slabs are sized from
+               kRetriedTotal,                                 // rows the retry launches have taken since the last reset
+               kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
                kGlobalLevels, kFailedRows, kDegLookups,
                kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
                kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
@@ -193,6 +200,11 @@ struct KParams {
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
     u32 long_len;                         // CSR ranges up to this length are 'short' (G lanes per range), longer ones take a wave
     int direct;                           // 1: every level's table is indexed by node id (N <= lds_slots; 512-thread kernel only)
+    // Two launches per call.  The first gives every workgroup a slab sized from an ESTIMATE of a row's needs; a row that
+    // outgrows it is not failed but appended to retry_list.  The second launch (a few workgroups, slabs sized from the
+    // rigorous bounds) takes its rows from that list: row_map / n_rows_dev are then set, retry_list is NULL and a
+    // row that still does not fit is reported (GP_ERR_OVERFLOW).
+    const u32* row_map; const u64* n_rows_dev; u32* retry_list; int queue_counter;
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
 
@@ -1290,7 +1302,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MI
     Cand* cand       = p.cand + wg * p.cand_cap;
 
     for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
-    if (tid < (int)(sizeof(ctl->st) / sizeof(ctl->st[0]))) ctl->st[tid] = 0;      // visible after the first row's barriers
+    if (tid < (int)(sizeof(ctl->st) / sizeof(ctl->st[0]))) { ctl->st[tid] = 0; ctl->st_row[tid] = 0; }      // visible after the first row's barriers
+    const long long n_rows = p.n_rows_dev ? (long long)*p.n_rows_dev : p.n_seeds;    // rows in this launch's queue
+    u32 max_e = 0, max_log = 0;                                                      // observed maxima of this workgroup
     u64 tk_scan = 0, tk_expand = 0, tk_topk = 0, tk_total = 0, t0 = 0, t1 = 0, t2 = 0, tk_begin = 0;
     u64 tk_scan_hbm = 0, tk_expand_hbm = 0; (void)tk_scan_hbm; (void)tk_expand_hbm;
     (void)tk_scan; (void)tk_expand; (void)tk_topk; (void)tk_total; (void)t0; (void)t1; (void)t2; (void)tk_begin;
@@ -1310,20 +1324,35 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MI
 #endif
         GP_SYNC();
         if (tid == 0) {
-            ctl->row = (long long)__hip_atomic_fetch_add(&p.counters[kQueue], 1ull, __ATOMIC_RELAXED,
+            ctl->row = (long long)__hip_atomic_fetch_add(&p.counters[p.queue_counter], 1ull, __ATOMIC_RELAXED,
                                                          __HIP_MEMORY_SCOPE_AGENT);
             ctl->log_count = 1;                         // record 0 is the seed's own (level 0, written below)
             ctl->n_cand = 0; ctl->fail = 0; ctl->ovf = 0;
             ctl->n_sel = 0; ctl->n_bucket = 0;
         }
         GP_SYNC();
-        const long long row = ctl->row;
-        if (row >= p.n_seeds) break;
+        const long long qpos = ctl->row;
+        if (qpos >= n_rows) break;
+        const long long row = p.row_map ? (long long)p.row_map[qpos] : qpos;
         const int seed = p.seeds[row];
         if (seed < 0 || seed >= p.n_nodes) {            // device API does not pre-validate seeds
-            if (tid == 0) { stat_add(ctl, sFailed, 1); if (p.out_filled) p.out_filled[row] = 0; }
+            if (tid == 0) { stat_add_final(ctl, sFailed, 1); if (p.out_filled) p.out_filled[row] = 0; }
             continue;
         }
+        // A row that ran out of workspace: first launch -> the retry list (its counts are dropped, the retry
+        // launch recounts the row); retry launch -> reported.  Returns with the row's statistics cleared.
+        auto give_up = [&]() {
+            if (tid == 0) {
+                if (p.retry_list) {
+                    const u64 i = __hip_atomic_fetch_add(&p.counters[kRetryRows], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    p.retry_list[i] = (u32)row;
+                } else {
+                    stat_add_final(ctl, sFailed, 1);
+                    if (p.out_filled) p.out_filled[row] = 0;
+                }
+            }
+            if (tid < (int)sNumStats) ctl->st_row[tid] = 0;
+        };
 
         // the seed's table key carries its degree like every packed column id
         const u32 seed_deg = (u32)(p.indptr[seed + 1] - p.indptr[seed]);
@@ -1395,6 +1424,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MI
             // distinct targets of this level <= min(edges (+ the seed), N)
             const u64 need = min((u64)e_cur + (has_dang_cur ? 1 : 0), (u64)p.n_nodes);
             if (need == 0) break;                       // the frontier died: later levels add nothing
+            max_e = max(max_e, e_cur);
             // placement of the level's residue table
             bool in_lds = !p.force_global;
             u32 parts = 1, cap = 0;
@@ -1596,13 +1626,16 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MI
             cur ^= 1;
         }
         GP_SYNC();
-        if (ctl->fail) {
-            // Leave the row unwritten and report it (GP_ERR_OVERFLOW).  Restore clean tables so
-            // that later rows of this workgroup are unaffected.
-            if (tid == 0) { stat_add(ctl, sFailed, 1); if (p.out_filled) p.out_filled[row] = 0; }
-            for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
-            for (u64 i = tid; i < p.resg_cap; i += BLOCK) { st_l2(&resg[i].key, kEmpty); st_l2(&resg[i].val, 0.0); }
-            continue;
+        {
+            const u32 failed = ctl->fail, n_log_row = ctl->log_count;      // one round trip
+            max_log = max(max_log, n_log_row);
+            if (failed) {
+                // Leave the row unwritten.  Restore clean tables so that later rows of this workgroup are unaffected.
+                give_up();
+                for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+                for (u64 i = tid; i < p.resg_cap; i += BLOCK) { st_l2(&resg[i].key, kEmpty); st_l2(&resg[i].val, 0.0); }
+                continue;
+            }
         }
         GP_STAMP(t0);
 #ifdef GP_DIAG
@@ -1615,7 +1648,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MI
 #endif
         topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, seg_begin, seg_len, n_levels, 0 GP_SUB_ARGS);
         GP_SYNC();
-        if (ctl->fail && tid == 0) stat_add(ctl, sFailed, 1);
+        if (ctl->fail) give_up();                                      // the candidate array overflowed: nothing was written
+        else if (tid < (int)sNumStats) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }      // the row is done: its counts count
         GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);
         // top-K used the table region as scratch: restore the empty LDS table
         for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
@@ -1632,6 +1666,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MI
 #pragma unroll
         for (int i = 0; i < sNumStats; ++i)
             if (ctl->st[i]) __hip_atomic_fetch_add(&p.counters[dst[i]], ctl->st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.row_map && blockIdx.x == 0 && n_rows > 0)
+            __hip_atomic_fetch_add(&p.counters[kRetriedTotal], (u64)n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (max_e) __hip_atomic_fetch_max(&p.counters[kMaxLevelEdges], (u64)max_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (max_log) __hip_atomic_fetch_max(&p.counters[kMaxLogRecords], (u64)max_log, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef GP_DIAG
         tk_total = wall_clock64() - tk_begin;
         __hip_atomic_fetch_add(&p.counters[kTicksScan], tk_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

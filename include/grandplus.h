@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GP_ABI_VERSION 1
+#define GP_ABI_VERSION 2
 
 /* Status codes (0 = success).  The Python / pybind11 shims map INVALID_* to
  * ValueError, NO_DEVICE / HIP / OVERFLOW to RuntimeError, NOMEM to MemoryError. */
@@ -65,6 +65,11 @@ typedef struct gp_stats {
     int64_t diag_ticks_scan, diag_ticks_expand, diag_ticks_topk, diag_ticks_total;
     int64_t diag_ticks_scan_hbm, diag_ticks_expand_hbm;   /* the part of scan/expand spent on HBM-table levels */
     int64_t diag_sub[16];    /* free-form sub-phase ticks / counts of the diagnostic build          */
+    /* ABI 2: workspace policy.  Every workgroup's scratch slab is sized from an estimate; rows that outgrow it are
+     * re-run by a second launch on a few workgroups whose slabs are sized from the rigorous 1/rmax bounds. */
+    int64_t retried_rows;    /* rows that took that second launch (they are complete and exact, just slower) */
+    int64_t max_level_edges; /* largest number of edges one level of one row traversed                       */
+    int64_t max_log_records; /* largest number of reserve-log records (sum over levels of frontier size) of one row */
 } gp_stats;
 
 /* ABI / build information. */
@@ -127,7 +132,11 @@ int gp_reset_stats(gp_graph* g);
  *   "block_threads"   256 | 512 | 1024      threads per persistent workgroup
  *   "lds_bytes"       dynamic LDS per workgroup (<= 163840)
  *   "max_workgroups"  upper bound on persistent workgroups (0 = CUs x resident blocks)
- *   "workspace_mb"    HBM scratch budget in MiB (default 65536)
+ *   "workspace_mb"    HBM scratch budget in MiB (default 65536, never more than 90 % of the free device memory).
+ *                      Under pressure the per-workgroup slabs shrink, not the number of workgroups; rows that
+ *                      outgrow their slab are re-run on a few workgroups with worst-case slabs (gp_stats.retried_rows)
+ *   "est_level_edges" edges per level the per-workgroup slabs are sized for (0 = automatic: max(32768, bound/4),
+ *                      grown from the observed maxima of earlier calls)
  *   "force_global"    1 = never use the LDS residue table (testing the HBM-table path)
  *   "max_degree_bits" cap on the spare column-id bits used to carry degrees (0 = none; testing the
  *                      path taken by graphs with N >= 2^29); only before the first gfpush call

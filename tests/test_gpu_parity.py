@@ -446,3 +446,52 @@ def test_candidate_values_outside_the_binade_counters(scale):
         exp, _ = _oracle(indptr, indices, seeds, coef, 1e-6, K)
         _assert_parity(seeds, K, got, exp)
         assert st["failed_rows"] == 0
+
+
+def test_workspace_is_sized_from_estimates_not_from_the_rmax_bound():
+    """the Cora recipe's rmax 1e-7 on a large graph.  The 1/rmax bound asks for ~190 MB of scratch per
+    workgroup here (97 GB for the launch); with a 4 GB budget the launch used to be cut to a few dozen workgroups.
+    Now every resident workgroup keeps a slab (sized from an estimate), the rows that outgrow it are re-run by the
+    retry launch on bound-sized slabs, and the rows are the oracle's."""
+    from grand_plus_amd import Graph, synth
+    from grand_plus_amd.recipes import RECIPES
+    from grand_plus_amd import _native
+    indptr, indices = synth.shape_csr("reddit")
+    r = RECIPES[("reddit", "single")]                      # order 2, rmax 1e-7, K 64 (scripts/run_reddit.sh:15)
+    assert r.rmax == 1e-7
+    seeds = synth.seeds(len(indptr) - 1, 1024)
+    K = r.top_k
+    g = Graph(indptr, indices, 0)
+    g.set_option("workspace_mb", 4096)
+    row = np.zeros(len(seeds) * K, np.int32); col = np.zeros(len(seeds) * K, np.int32); val = np.zeros(len(seeds) * K)
+    g.gfpush_omp(seeds, row, col, val, r.coef(), r.rmax, K)
+    st = g.stats()
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert st["workgroups"] >= min(cus, len(seeds)) and st["failed_rows"] == 0
+    assert st["workspace_bytes"] < 4 * 2**30
+    exp, ost = _oracle(indptr, indices, seeds, r.coef(), r.rmax, K)
+    _assert_parity(seeds, K, (row, col, val), exp)
+    assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"] and st["filled"] == ost["filled"]
+    # forcing a tiny estimate sends (nearly) every row through the retry launch: same rows, same exact counters
+    g2 = Graph(indptr, indices, 0)
+    g2.set_option("workspace_mb", 4096); g2.set_option("est_level_edges", 64)
+    row2 = np.zeros_like(row); col2 = np.zeros_like(col); val2 = np.zeros_like(val)
+    g2.gfpush_omp(seeds, row2, col2, val2, r.coef(), r.rmax, K)
+    st2 = g2.stats()
+    assert st2["retried_rows"] > len(seeds) // 2 and st2["failed_rows"] == 0
+    _assert_parity(seeds, K, (row2, col2, val2), exp)
+    assert st2["pushes"] == ost["pushes"] and st2["edges"] == ost["edges"] and st2["filled"] == ost["filled"]
+
+
+def test_lds_budget_too_small_for_topk_is_rejected():
+    """lds_bytes near 40 KB with a large K left the top-K aggregation table smaller than a probe span."""
+    from grand_plus_amd import Graph, synth
+    indptr, indices = synth.shape_csr("tiny")
+    g = Graph(indptr, indices, 0)
+    g.set_option("block_threads", 256); g.set_option("lds_bytes", 40960)
+    seeds = synth.seeds(len(indptr) - 1, 8)
+    K = 1000
+    row = np.zeros(8 * K, np.int32); col = np.zeros(8 * K, np.int32); val = np.zeros(8 * K)
+    with pytest.raises(ValueError, match="too small for K"):
+        g.gfpush_omp(seeds, row, col, val, np.array([0.5, 0.5]), 1e-4, K)

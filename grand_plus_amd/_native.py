@@ -27,6 +27,7 @@ EXPORTS = (
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
+    "gp_graph_create_multi", "gp_graph_num_gpus",
 )
 
 
@@ -83,6 +84,10 @@ def lib():
     L.gp_graph_create.restype = ctypes.c_int
     L.gp_graph_create.argtypes = [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.c_int,
                                   ctypes.POINTER(vp)]
+    L.gp_graph_create_multi.restype = ctypes.c_int
+    L.gp_graph_create_multi.argtypes = [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(vp)]
+    L.gp_graph_num_gpus.restype = ctypes.c_int
+    L.gp_graph_num_gpus.argtypes = [vp]
     L.gp_graph_destroy.restype = None
     L.gp_graph_destroy.argtypes = [vp]
     L.gp_graph_num_nodes.restype = ctypes.c_int64

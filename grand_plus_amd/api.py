@@ -46,7 +46,10 @@ def _ptr(a, ct):
 class Graph:
     """CSR graph resident in one MI355X's HBM.  Mirrors `propagation.Graph`."""
 
-    def __init__(self, indptr, indices, seed=0, device=None):
+    def __init__(self, indptr, indices, seed=0, device=None, n_gpus=None):
+        """`n_gpus` = None: one GPU (`device`, the form every rank of the torch.distributed driver uses).
+        `n_gpus` = 0 / N: a multi-GPU handle over all / the first N visible GPUs (`gp_graph_create_multi`):
+        `gfpush_omp` then shards its seeds over them inside the one call (RCCL all-gather of the rows)."""
         L = _native.lib()
         ip = _as_i32_readonly(indptr, "indptr")
         ix = _as_i32_readonly(indices, "indices")
@@ -59,13 +62,20 @@ class Graph:
             if device >= max(L.gp_device_count(), 1):
                 device = 0
         h = ctypes.c_void_p()
-        _native.raise_for_status(L.gp_graph_create(_ptr(ip, ctypes.c_int32), ip.size - 1,
-                                                   _ptr(ix, ctypes.c_int32), ix.size, int(device),
-                                                   ctypes.byref(h)))
+        if n_gpus is None:
+            _native.raise_for_status(L.gp_graph_create(_ptr(ip, ctypes.c_int32), ip.size - 1,
+                                                       _ptr(ix, ctypes.c_int32), ix.size, int(device),
+                                                       ctypes.byref(h)))
+        else:
+            _native.raise_for_status(L.gp_graph_create_multi(_ptr(ip, ctypes.c_int32), ip.size - 1,
+                                                             _ptr(ix, ctypes.c_int32), ix.size, int(n_gpus),
+                                                             ctypes.byref(h)))
+            device = L.gp_graph_device(h)
         self._h = h
         self.num_nodes = ip.size - 1
         self.nnz = ix.size
         self.device = int(device)
+        self.n_gpus = L.gp_graph_num_gpus(h)
 
     def close(self):
         if getattr(self, "_h", None):

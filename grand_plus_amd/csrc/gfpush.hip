@@ -9,6 +9,9 @@
 #include "gfpush_kernels.hpp"
 #include "grandplus.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is opened with dlopen when a second GPU is first used
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -97,6 +100,14 @@ struct gp_graph {
     bool reset_pending = true; int64_t rows_total = 0;
     gp_stats last{};
     // staging for the host-buffer entry point
+    // ---- multi-GPU handle (gp_graph_create_multi): this object then owns no device memory itself; part[0] holds the CSR
+    //      on the first GPU, the other GPUs get their replica (peer copy) the first time a call is large enough to shard.
+    bool multi = false; int n_parts = 0; int force_collective = 0; int gather_host = 0; int64_t min_rows_per_gpu = 2048;
+    std::vector<gp_graph*> part; std::vector<int> devices;
+    std::vector<ncclComm_t> comms; bool comms_ready = false;
+    std::vector<char*> m_slab, m_gather; std::vector<int*> m_seeds; size_t m_stride = 0; int64_t m_per = 0;
+    char* m_host = nullptr; size_t m_host_bytes = 0;
+    gp_stats m_last{}; bool m_has_stats = false;
     // one packed slab [val f64 x slots | row i32 x slots | col i32 x slots | filled i32 x seeds] on the device and one pinned
     // mirror: the rows come back with ONE D2H copy (the layout grand_plus_amd/sharded.py all-gathers)
     int* d_seeds = nullptr; int64_t seeds_cap = 0;
@@ -255,6 +266,51 @@ int check_call_args(const gp_graph* g, int64_t n_seeds, const double* coef, int 
     return GP_OK;
 }
 
+// ------------------------------------------------------------------ RCCL, opened on demand
+// The single-GPU path must not depend on RCCL being loadable, and a Python process has usually mapped torch's own
+// librccl.so.1 already (same soname: dlopen returns that copy, one RCCL per process).
+int gfpush_multi(gp_graph* g, const int32_t* seeds, int64_t n_seeds, const double* coef, int n_coef, double rmax, int K,
+                 int32_t* row_idx, int32_t* col_idx, double* value);
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.h) return GP_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(GP_ERR_HIP, "multi-GPU gather needs RCCL: dlopen(librccl.so.1) failed: %s", dlerror());
+    Rccl r; r.h = h;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
+        return fail(GP_ERR_HIP, "librccl.so.1 lacks a required symbol");
+    g_rccl = r;
+    return GP_OK;
+}
+
+#define RCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess) return fail(GP_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+// bytes one GPU contributes to the gather: [val f64 | row i32 | col i32 | filled i32] for `per` rows, 16-byte padded
+// (the layout of grand_plus_amd/sharded.py:packed_stride, so both multi-GPU drivers move the same slab)
+size_t packed_stride(int64_t per, int K) { return ((size_t)16 * per * K + (size_t)4 * per + 15) / 16 * 16; }
+
 }  // namespace
 
 extern "C" {
@@ -357,6 +413,20 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
 
 void gp_graph_destroy(gp_graph* g) {
     if (!g) return;
+    if (g->multi) {
+        for (size_t d = 0; d < g->comms.size(); ++d) if (g->comms[d]) (void)g_rccl.CommDestroy(g->comms[d]);
+        for (size_t d = 0; d < g->part.size(); ++d) {
+            if (!g->part[d]) continue;
+            (void)hipSetDevice(g->devices[d]);
+            if (d < g->m_slab.size() && g->m_slab[d]) (void)hipFree(g->m_slab[d]);
+            if (d < g->m_gather.size() && g->m_gather[d]) (void)hipFree(g->m_gather[d]);
+            if (d < g->m_seeds.size() && g->m_seeds[d]) (void)hipFree(g->m_seeds[d]);
+            gp_graph_destroy(g->part[d]);
+        }
+        if (g->m_host) (void)hipHostFree(g->m_host);
+        delete g;
+        return;
+    }
     (void)hipSetDevice(g->device);
     if (g->launched) (void)hipStreamSynchronize(g->last_stream);
     free_workspace(g->ws);
@@ -376,11 +446,22 @@ void gp_graph_destroy(gp_graph* g) {
 
 int64_t gp_graph_num_nodes(const gp_graph* g) { return g ? g->n_nodes : -1; }
 int64_t gp_graph_nnz(const gp_graph* g) { return g ? g->nnz : -1; }
-int gp_graph_device(const gp_graph* g) { return g ? g->device : -1; }
+int gp_graph_device(const gp_graph* g) { return g ? (g->multi ? g->devices[0] : g->device) : -1; }
+int gp_graph_num_gpus(const gp_graph* g) { return g ? (g->multi ? g->n_parts : 1) : -1; }
 
 int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     if (!g || !key) return fail(GP_ERR_NULL, "null argument");
     const std::string k(key);
+    if (g->multi) {
+        if (k == "force_collective") { g->force_collective = value ? 1 : 0; return GP_OK; }
+        if (k == "gather_host") { g->gather_host = value ? 1 : 0; return GP_OK; }
+        if (k == "min_rows_per_gpu") {
+            if (value < 1) return fail(GP_ERR_INVALID_ARG, "min_rows_per_gpu must be >= 1");
+            g->min_rows_per_gpu = value; return GP_OK;
+        }
+        for (gp_graph* q : g->part) if (q) { int rc = gp_set_option(q, key, value); if (rc) return rc; }
+        return GP_OK;
+    }
     if (k == "block_threads") {
         if (value != 256 && value != 512 && value != 768 && value != 1024) return fail(GP_ERR_INVALID_ARG, "block_threads must be 256, 512, 768 or 1024");
         g->block_threads = (int)value;
@@ -421,6 +502,8 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     g_last_error.clear();
     int rc = check_call_args(g, n_seeds, coef, n_coef, rmax, K);
     if (rc) return rc;
+    if (g->multi) return fail(GP_ERR_INVALID_ARG, "gp_gfpush_device needs a single-GPU graph (device buffers live on one GPU); "
+                                                  "a multi-GPU handle takes host buffers through gp_gfpush");
     if (n_seeds > 0 && (!d_seeds || !d_row || !d_col || !d_val)) return fail(GP_ERR_NULL, "a device buffer is NULL");
     HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = (hipStream_t)stream;
@@ -569,12 +652,19 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
 
 int gp_reset_stats(gp_graph* g) {
     if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
+    if (g->multi) { for (gp_graph* q : g->part) if (q) (void)gp_reset_stats(q); g->m_has_stats = false; return GP_OK; }
     g->reset_pending = true;
     return GP_OK;
 }
 
 int gp_get_stats(gp_graph* g, gp_stats* out) {
     if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
+    if (g->multi) {                                         // what the last gp_gfpush on the handle added up over its GPUs
+        if (out) { if (g->m_has_stats) *out = g->m_last; else std::memset(out, 0, sizeof *out); }
+        if (g->m_has_stats && g->m_last.failed_rows)
+            return fail(GP_ERR_OVERFLOW, "%lld row(s) hit a workspace bound", (long long)g->m_last.failed_rows);
+        return GP_OK;
+    }
     if (!g->launched) { if (out) std::memset(out, 0, sizeof *out); return GP_OK; }
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipStreamSynchronize(g->last_stream));
@@ -627,6 +717,7 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
     for (int64_t i = 0; i < n_seeds; ++i)
         if (seeds[i] < 0 || seeds[i] >= g->n_nodes)
             return fail(GP_ERR_INVALID_SEED, "node_idx[%lld] = %d outside [0, %lld)", (long long)i, seeds[i], (long long)g->n_nodes);
+    if (g->multi) return gfpush_multi(g, seeds, n_seeds, coef, n_coef, rmax, K, row_idx, col_idx, value);
     HIP_TRY(hipSetDevice(g->device));
     const int64_t slots = n_seeds * (int64_t)K;
     if (n_seeds > g->seeds_cap) {
@@ -683,4 +774,202 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
     return GP_OK;
 }
 
+int gp_graph_create_multi(const int32_t* indptr, int64_t n_nodes, const int32_t* indices, int64_t nnz,
+                          int n_gpus, gp_graph** out)
+{
+    g_last_error.clear();
+    if (!out) return fail(GP_ERR_NULL, "out is NULL");
+    *out = nullptr;
+    const int ndev = gp_device_count();
+    if (ndev <= 0) return fail(GP_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
+    if (n_gpus < 0 || n_gpus > ndev) return fail(GP_ERR_NO_DEVICE, "n_gpus = %d but %d device(s) are visible", n_gpus, ndev);
+    if (n_gpus == 0) n_gpus = ndev;
+    gp_graph* first = nullptr;
+    int rc = gp_graph_create(indptr, n_nodes, indices, nnz, 0, &first);       // validates and uploads once
+    if (rc) return rc;
+    gp_graph* g = new (std::nothrow) gp_graph();
+    if (!g) { gp_graph_destroy(first); return fail(GP_ERR_NOMEM, "host allocation failed"); }
+    g->multi = true; g->n_parts = n_gpus; g->n_nodes = n_nodes; g->nnz = nnz;
+    g->part.assign(n_gpus, nullptr); g->devices.resize(n_gpus);
+    for (int d = 0; d < n_gpus; ++d) g->devices[d] = d;
+    g->part[0] = first;
+    g->comms.assign(n_gpus, nullptr);
+    g->m_slab.assign(n_gpus, nullptr); g->m_gather.assign(n_gpus, nullptr); g->m_seeds.assign(n_gpus, nullptr);
+    *out = g;
+    return GP_OK;
+}
+
 }  // extern "C"
+
+namespace {
+
+// Replica of part[0]'s CSR on another GPU: device-to-device copy (xGMI), no second pass over the host arrays.
+int replicate_part(gp_graph* g, int d) {
+    gp_graph* src = g->part[0];
+    HIP_TRY(hipSetDevice(src->device));
+    int rc = ensure_packed(src, src->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    const int dev = g->devices[d];
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    gp_graph* q = new (std::nothrow) gp_graph();
+    if (!q) return fail(GP_ERR_NOMEM, "host allocation failed");
+    g->part[d] = q;                                        // owned from here on (destroyed with the handle)
+    q->device = dev; q->n_nodes = src->n_nodes; q->nnz = src->nnz; q->num_cus = prop.multiProcessorCount;
+    q->deg_shift = src->deg_shift; q->node_mask = src->node_mask; q->deg_sat = src->deg_sat;
+    q->packed = true; q->max_degree_bits = src->max_degree_bits;
+    q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
+    q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
+    q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges;
+    const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)std::max<int64_t>(q->nnz, 1);
+    HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
+    HIP_TRY(hipMalloc(&q->d_indices, b_idx));
+    HIP_TRY(hipMemcpyPeer(q->d_indptr, dev, src->d_indptr, src->device, b_ptr));
+    HIP_TRY(hipMemcpyPeer(q->d_indices, dev, src->d_indices, src->device, b_idx));
+    HIP_TRY(hipMalloc(&q->d_counters, sizeof(u64) * kNumCounters));
+    HIP_TRY(hipHostMalloc(&q->h_counters, sizeof(u64) * kNumCounters));
+    HIP_TRY(hipEventCreate(&q->ev0));
+    HIP_TRY(hipEventCreate(&q->ev1));
+    HIP_TRY(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+    return GP_OK;
+}
+
+void scatter_filled(const char* slab, int64_t per, int K, int64_t row0, int64_t n_rows,
+                    int32_t* row_idx, int32_t* col_idx, double* value)
+{
+    const size_t slots = (size_t)per * K;
+    const double* h_val = (const double*)slab; const int* h_row = (const int*)(slab + 8 * slots);
+    const int* h_col = (const int*)(slab + 12 * slots); const int* h_filled = (const int*)(slab + 16 * slots);
+    for (int64_t it = 0; it < n_rows; ++it) {
+        const int nf = h_filled[it];
+        if (nf <= 0) continue;                             // graph.h:121: only v > 0 slots are written
+        const size_t o = (size_t)it * K, oo = (size_t)(row0 + it) * K;
+        std::memcpy(row_idx + oo, h_row + o, sizeof(int) * (size_t)nf);
+        std::memcpy(col_idx + oo, h_col + o, sizeof(int) * (size_t)nf);
+        std::memcpy(value + oo, h_val + o, sizeof(double) * (size_t)nf);
+    }
+}
+
+// gfpush_omp on a multi-GPU handle: the caller's ONE call (model.py:268) uses every GPU of the node.
+// Seeds are cut into n_parts contiguous blocks of ceil(S / n_parts) rows; one host thread per GPU uploads its block
+// and launches the same kernels on its own stream, writing into that GPU's packed slab; ONE ncclAllGather of the
+// slabs (RCCL over xGMI) reassembles the sparse row matrix on every GPU, GPU 0 copies it to the host in one D2H and
+// the v > 0 slots are scattered into the caller's arrays.  Option "gather_host" = 1 skips the collective and lets
+// every GPU copy its own slab to the host (the comparison SURVEY.md 8e asks to keep).
+int gfpush_multi(gp_graph* g, const int32_t* seeds, int64_t n_seeds, const double* coef, int n_coef, double rmax, int K,
+                 int32_t* row_idx, int32_t* col_idx, double* value)
+{
+    int G = g->n_parts;
+    if (n_seeds < g->min_rows_per_gpu * (int64_t)G && !g->force_collective) G = 1;     // small calls stay on one GPU
+    if (G == 1 && !g->force_collective) {
+        int rc = gp_gfpush(g->part[0], seeds, n_seeds, coef, n_coef, rmax, K, row_idx, col_idx, value);
+        gp_stats st; const int rc2 = gp_get_stats(g->part[0], &st);
+        g->m_last = st; g->m_has_stats = true;
+        return rc ? rc : rc2;
+    }
+    for (int d = 1; d < G; ++d)
+        if (!g->part[d]) { int rc = replicate_part(g, d); if (rc) return rc; }
+    const bool collective = !g->gather_host;
+    if (collective && !g->comms_ready) {
+        int rc = load_rccl();
+        if (rc) return rc;
+        RCCL_TRY(g_rccl.CommInitAll(g->comms.data(), g->n_parts, g->devices.data()));
+        g->comms_ready = true;
+    }
+    const int64_t per = (n_seeds + G - 1) / G;
+    const size_t stride = packed_stride(per, K);
+    const int Gc = collective ? g->n_parts : G;            // the communicator spans every GPU of the handle
+    if (stride > g->m_stride || per > g->m_per) {          // m_stride / m_per: CAPACITY of the per-GPU buffers (bytes / seeds)
+        for (int d = 0; d < g->n_parts; ++d) {
+            if (!g->part[d]) { if (d < Gc) { int rc = replicate_part(g, d); if (rc) return rc; } else continue; }
+            HIP_TRY(hipSetDevice(g->devices[d]));
+            if (g->m_slab[d]) (void)hipFree(g->m_slab[d]);
+            if (g->m_gather[d]) (void)hipFree(g->m_gather[d]);
+            if (g->m_seeds[d]) (void)hipFree(g->m_seeds[d]);
+            g->m_slab[d] = g->m_gather[d] = nullptr; g->m_seeds[d] = nullptr;
+            HIP_TRY(hipMalloc(&g->m_slab[d], stride));
+            HIP_TRY(hipMalloc(&g->m_gather[d], stride * (size_t)g->n_parts));
+            HIP_TRY(hipMalloc(&g->m_seeds[d], sizeof(int) * (size_t)std::max<int64_t>(std::max(per, g->m_per), 1)));
+        }
+        g->m_per = std::max(per, g->m_per); g->m_stride = stride;
+        if (g->m_host) (void)hipHostFree(g->m_host);
+        g->m_host = nullptr; g->m_host_bytes = 0;
+        HIP_TRY(hipSetDevice(g->devices[0]));
+        HIP_TRY(hipHostMalloc(&g->m_host, stride * (size_t)g->n_parts));
+        g->m_host_bytes = stride * (size_t)g->n_parts;
+    } else if (collective) {
+        for (int d = 0; d < Gc; ++d) if (!g->part[d]) { int rc = replicate_part(g, d); if (rc) return rc; }
+    }
+    const size_t cur_stride = stride;                      // this call's layout (the buffers may be larger)
+    const int64_t cur_per = per;
+    const size_t slots = (size_t)cur_per * K;
+
+    std::vector<int> rcs(Gc, GP_OK);
+    std::vector<std::string> errs(Gc);
+    std::vector<std::thread> pool;
+    const int64_t blk = (n_seeds + G - 1) / G;             // rows per computing GPU
+    auto work = [&](int d) {
+        gp_graph* q = g->part[d];
+        const int64_t lo = std::min<int64_t>((int64_t)d * blk, n_seeds), hi = d < G ? std::min<int64_t>(lo + blk, n_seeds) : lo;
+        const int64_t n = hi - lo;
+        auto run = [&]() -> int {
+            HIP_TRY(hipSetDevice(q->device));
+            char* slab = g->m_slab[d];
+            HIP_TRY(hipMemsetAsync(slab + 16 * slots, 0, 4 * (size_t)cur_per, q->stream));          // filled[] = 0
+            if (n > 0) {
+                HIP_TRY(hipMemcpyAsync(g->m_seeds[d], seeds + lo, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, q->stream));
+                q->reset_pending = true;
+                int rc = gp_gfpush_device(q, g->m_seeds[d], n, coef, n_coef, rmax, K, (int*)(slab + 8 * slots),
+                                          (int*)(slab + 12 * slots), (double*)slab, (int*)(slab + 16 * slots), q->stream);
+                if (rc) return rc;
+            }
+            if (!collective) HIP_TRY(hipMemcpyAsync(g->m_host + (size_t)d * cur_stride, slab, cur_stride, hipMemcpyDeviceToHost, q->stream));
+            return GP_OK;
+        };
+        rcs[d] = run();
+        if (rcs[d]) errs[d] = g_last_error;                // g_last_error is thread-local
+    };
+    for (int d = 1; d < Gc; ++d) pool.emplace_back(work, d);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (int d = 0; d < Gc; ++d) if (rcs[d]) { g_last_error = errs[d]; return rcs[d]; }
+
+    if (collective) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int d = 0; d < Gc; ++d)
+            RCCL_TRY(g_rccl.AllGather(g->m_slab[d], g->m_gather[d], cur_stride, ncclUint8, g->comms[d], g->part[d]->stream));
+        RCCL_TRY(g_rccl.GroupEnd());
+        HIP_TRY(hipSetDevice(g->devices[0]));
+        HIP_TRY(hipMemcpyAsync(g->m_host, g->m_gather[0], cur_stride * (size_t)Gc, hipMemcpyDeviceToHost, g->part[0]->stream));
+    }
+    // wait for every GPU and add up the counters
+    gp_stats sum; std::memset(&sum, 0, sizeof sum);
+    int status = GP_OK;
+    for (int d = 0; d < Gc; ++d) {
+        gp_graph* q = g->part[d];
+        HIP_TRY(hipSetDevice(q->device));
+        HIP_TRY(hipStreamSynchronize(q->stream));
+        if (!q->launched || d >= G) continue;
+        gp_stats st; const int rc = gp_get_stats(q, &st);
+        if (rc && !status) status = rc;
+        sum.rows += st.rows; sum.pushes += st.pushes; sum.edges += st.edges; sum.filled += st.filled; sum.support += st.support;
+        sum.frontier += st.frontier; sum.lds_levels += st.lds_levels; sum.global_levels += st.global_levels;
+        sum.failed_rows += st.failed_rows; sum.degree_lookups += st.degree_lookups; sum.retried_rows += st.retried_rows;
+        sum.kernel_ms = std::max(sum.kernel_ms, st.kernel_ms); sum.workgroups += st.workgroups;
+        sum.block_threads = st.block_threads; sum.lds_bytes = st.lds_bytes; sum.lds_slots = st.lds_slots;
+        sum.workspace_bytes += st.workspace_bytes;
+        sum.max_level_edges = std::max(sum.max_level_edges, st.max_level_edges);
+        sum.max_log_records = std::max(sum.max_log_records, st.max_log_records);
+    }
+    g->m_last = sum; g->m_has_stats = true;
+    if (status) return status;
+    for (int d = 0; d < G; ++d) {
+        const int64_t lo = std::min<int64_t>((int64_t)d * blk, n_seeds), hi = std::min<int64_t>(lo + blk, n_seeds);
+        scatter_filled(g->m_host + (size_t)d * cur_stride, cur_per, K, lo, hi - lo, row_idx, col_idx, value);
+    }
+    return GP_OK;
+}
+
+}  // namespace

@@ -55,14 +55,26 @@ public:
           py::array_t<int, py::array::c_style | py::array::forcecast> indices, int /*seed: unused, graph.h:40*/)
     {
         if (indptr.size() < 1) throw py::value_error("indptr must have at least one element");
-        int device = 0;
-        if (const char* e = std::getenv("GRANDPLUS_DEVICE")) device = std::atoi(e);
-        else if (const char* r = std::getenv("LOCAL_RANK")) device = std::atoi(r);
-        if (device >= gp_device_count()) device = 0;
+        // The reference's caller is one process making one call (model.py:251, :268): by default that call gets the whole
+        // node -- a multi-GPU handle over every visible GPU (small calls stay on GPU 0 and never touch the others).
+        // GRANDPLUS_GPUS=N restricts it to N GPUs; GRANDPLUS_DEVICE / LOCAL_RANK pin ONE GPU (a rank of a
+        // one-process-per-GPU launch must not grab its neighbours' devices).
+        const char* pin = std::getenv("GRANDPLUS_DEVICE");
+        if (!pin) pin = std::getenv("LOCAL_RANK");
+        const int ndev = gp_device_count();
+        int n_gpus = ndev;
+        if (const char* e = std::getenv("GRANDPLUS_GPUS")) n_gpus = std::atoi(e);
+        if (n_gpus < 1 || n_gpus > ndev) n_gpus = ndev;
         int rc;
         {
             py::gil_scoped_release nogil;
-            rc = gp_graph_create(indptr.data(), indptr.size() - 1, indices.data(), indices.size(), device, &g_);
+            if (pin || ndev <= 1) {
+                int device = pin ? std::atoi(pin) : 0;
+                if (device < 0 || device >= ndev) device = 0;
+                rc = gp_graph_create(indptr.data(), indptr.size() - 1, indices.data(), indices.size(), device, &g_);
+            } else {
+                rc = gp_graph_create_multi(indptr.data(), indptr.size() - 1, indices.data(), indices.size(), n_gpus, &g_);
+            }
         }
         if (rc != GP_OK) raise_status(rc);
     }

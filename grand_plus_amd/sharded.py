@@ -60,13 +60,17 @@ def unpack_gathered(gathered, world: int, per: int, K: int, n_seeds: int):
 
 
 def gfpush_sharded(compute, seeds_local, per: int, K: int, n_seeds: int, device, group=None,
-                   packed: PackedRows | None = None, gathered=None):
+                   packed: PackedRows | None = None, gathered=None, failed_rows=None):
     """Run `compute` on this rank's shard and all-gather the packed rows.
 
     compute(seeds_local, row, col, val, filled) must fill the first len(seeds_local) rows of
     the given views (dense per row for the first filled[it] slots) -- `Graph.gfpush_device`
     bound to its coef/rmax/K is the product path; tests inject a CPU stand-in under gloo.
-    Returns (row, col, val, filled) for all n_seeds rows, on every rank.
+    Returns (row, col, val, filled) for all n_seeds rows, on every rank.  Slots i >= filled[it] of a row hold
+    whatever the buffer held before (a re-used `packed` keeps the previous step's data there): consumers mask by
+    `filled`.  `failed_rows` (a callable returning this rank's count of rows that hit a workspace bound, e.g.
+    `lambda: graph.stats()["failed_rows"]` -- it synchronises) makes a failure on ANY rank raise on EVERY rank
+    instead of travelling through the gather as valid-looking empty rows.
     """
     import torch
     import torch.distributed as dist
@@ -78,6 +82,17 @@ def gfpush_sharded(compute, seeds_local, per: int, K: int, n_seeds: int, device,
         packed.filled.zero_()
     if seeds_local.numel() > 0:
         compute(seeds_local, packed.row, packed.col, packed.val, packed.filled)
+    if failed_rows is not None:
+        try:
+            bad = int(failed_rows())
+        except RuntimeError:                            # Graph.stats() raises for failed rows on this rank
+            bad = 1
+        if world > 1:
+            t = torch.tensor([bad], dtype=torch.int64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            bad = int(t.item())
+        if bad:
+            raise RuntimeError(f"{bad} row(s) hit a workspace bound on some rank (GP_ERR_OVERFLOW); the gathered rows are incomplete")
     if world == 1:
         return unpack_gathered(packed.buf[:packed.nbytes], 1, per, K, n_seeds)
     if gathered is None:

@@ -89,6 +89,27 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes,
                     const int32_t* indices, int64_t nnz,
                     int device, gp_graph** out);
 
+/*
+ * Multi-GPU form of the same constructor: ONE process, ONE call, every GPU of the node.
+ * n_gpus = 0 means all visible devices.  The CSR is uploaded to GPU 0; the other GPUs receive their replica by a
+ * device-to-device copy the first time a gp_gfpush call is large enough to be sharded (>= "min_rows_per_gpu" rows per
+ * GPU, default 2048; smaller calls run on GPU 0 alone).  gp_gfpush on such a handle cuts the seeds into contiguous
+ * blocks of ceil(S / n_gpus) rows, runs every block on its GPU from its own host thread and stream, reassembles the
+ * sparse row matrix with ONE ncclAllGather (RCCL over xGMI) of the packed per-GPU slabs
+ * [value f64 | row i32 | col i32 | filled i32], copies it to the host once from GPU 0 and writes the v > 0 slots into
+ * the caller's arrays (graph.h:117-126).  RCCL is opened with dlopen the first time it is needed.
+ * gp_gfpush_device is refused on a multi-GPU handle (device buffers live on one GPU).  Extra options of such a handle:
+ *   "min_rows_per_gpu"  sharding threshold (default 2048)
+ *   "gather_host"       1 = no collective: every GPU copies its own slab to the host (measured comparison)
+ *   "force_collective"  1 = take the sharded path, all-gather included, even for small calls / one GPU (tests)
+ * every other option is forwarded to the per-GPU graphs.  gp_get_stats returns the sums over the GPUs of the last call
+ * (kernel_ms = the slowest GPU).
+ */
+int gp_graph_create_multi(const int32_t* indptr, int64_t n_nodes,
+                          const int32_t* indices, int64_t nnz,
+                          int n_gpus, gp_graph** out);
+int gp_graph_num_gpus(const gp_graph* g);
+
 void gp_graph_destroy(gp_graph* g);
 
 int64_t gp_graph_num_nodes(const gp_graph* g);

@@ -495,3 +495,40 @@ def test_lds_budget_too_small_for_topk_is_rejected():
     row = np.zeros(8 * K, np.int32); col = np.zeros(8 * K, np.int32); val = np.zeros(8 * K)
     with pytest.raises(ValueError, match="too small for K"):
         g.gfpush_omp(seeds, row, col, val, np.array([0.5, 0.5]), 1e-4, K)
+
+
+def test_multi_gpu_handle_one_call_uses_every_gpu():
+    """gp_graph_create_multi: seeds block-partitioned over the GPUs inside ONE gfpush_omp call, one
+    ncclAllGather of the packed slabs, one D2H.  On a single-GPU box the same path runs with a one-rank
+    communicator ("force_collective"); with >= 2 GPUs the rows are really sharded.  Either way they must equal the
+    single-GPU rows and the oracle's, and the exact counters must add up."""
+    from grand_plus_amd import Graph, synth, _native
+    from grand_plus_amd.recipes import RECIPES
+    indptr, indices = synth.shape_csr("small")
+    r = RECIPES[("mag", "ppr")]
+    K = r.top_k
+    n_dev = _native.lib().gp_device_count()
+    seeds = synth.seeds(len(indptr) - 1, 1000 + 37 * n_dev)              # ragged: the last block is shorter
+    single, st1 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, K, fill=(-1, -1, -1.0))
+    for opts in ({"force_collective": 1, "min_rows_per_gpu": 64}, {"gather_host": 1, "force_collective": 1, "min_rows_per_gpu": 64}):
+        g = Graph(indptr, indices, 0, n_gpus=0)
+        assert g.n_gpus == n_dev
+        for k, v in opts.items():
+            g.set_option(k, v)
+        row = np.full(len(seeds) * K, -1, np.int32); col = np.full(len(seeds) * K, -1, np.int32); val = np.full(len(seeds) * K, -1.0)
+        g.gfpush_omp(seeds, row, col, val, r.coef(), r.rmax, K)
+        st = g.stats()
+        _assert_parity(seeds, K, (row, col, val), single, fill=(-1, -1, -1.0))
+        assert st["rows"] == len(seeds) and st["failed_rows"] == 0
+        assert (st["pushes"], st["edges"], st["filled"]) == (st1["pushes"], st1["edges"], st1["filled"])
+        # a second, smaller call re-uses the buffers; a call below the sharding threshold stays on GPU 0
+        g.set_option("force_collective", 0); g.set_option("min_rows_per_gpu", 1 << 20)
+        row2 = np.full(64 * K, -1, np.int32); col2 = np.full(64 * K, -1, np.int32); val2 = np.full(64 * K, -1.0)
+        g.gfpush_omp(seeds[:64], row2, col2, val2, r.coef(), r.rmax, K)
+        _assert_parity(seeds[:64], K, (row2, col2, val2), (row[:64 * K], col[:64 * K], val[:64 * K]), fill=(-1, -1, -1.0))
+        with pytest.raises(ValueError, match="single-GPU"):
+            import torch
+            g.gfpush_device(torch.zeros(4, dtype=torch.int32, device="cuda"), r.coef(), r.rmax, K)
+        g.close()
+    exp, _ = _oracle(indptr, indices, seeds, r.coef(), r.rmax, K, fill=(-1, -1, -1.0))
+    _assert_parity(seeds, K, single, exp, fill=(-1, -1, -1.0))

@@ -121,6 +121,47 @@ def cpu_baseline(indptr, indices, seeds, recipe, budget_s: float = 12.0):
     return out
 
 
+def next_rows(graph, packed, per, K, n_nodes, nnz, dev):
+    """One measured line each for the two SURVEY.md 8(f) kernels that consume this path's output, on the data the
+    benchmark has resident: the fused feature augmentation (random_prop, model.py:80-87) over the rows GFPush just
+    wrote, validation-sized batch (model.py:143), and two steps of predict()'s exact propagation (model.py:186-210)
+    on the resident CSR.  HBM-gather bound, algorithmic bytes as in bench_augment.py / bench_propagate.py."""
+    import torch
+    from grand_plus_amd.augment import algorithmic_bytes as aug_bytes, random_prop_rows
+    out = {}
+
+    def timed(fn, iters):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record(); torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / iters
+
+    try:
+        F, B = 128, min(10000, per)
+        X = torch.randn((n_nodes, F), device=dev)
+        rows = (torch.arange(B, dtype=torch.int64) * 7919 % per).to(torch.int32).to(dev)
+        ms = timed(lambda: random_prop_rows(X, packed.col, packed.val, packed.filled, K, batch_rows=rows, training=False), 20)
+        kept = int(packed.filled[rows.long()].sum().item())
+        by = aug_bytes(kept, B, F)
+        out["augment"] = {"kernel": "random_prop_rows_kernel", "batch_rows": B, "K": K, "feat_dim": F, "ms": round(ms, 4),
+                          "achieved_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        Fp, steps = 32, 2
+        Xp = X[:, :Fp].contiguous()
+        outp = torch.empty_like(Xp)
+        ms = timed(lambda: graph.propagate_features(Xp, "ppr", steps, 0.2, out=outp), 2)
+        by = (4 * Fp * nnz + 4 * nnz + 12 * n_nodes * Fp) * steps
+        out["propagate"] = {"kernel": "spmm_kernel", "feat_dim": Fp, "steps": steps, "ms_per_step": round(ms / steps, 3),
+                            "achieved_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    except Exception as e:                                   # never lose the headline line to a side measurement
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -158,6 +199,7 @@ def parse_args():
     ap.add_argument("--seeds-per-gpu", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the augmentation / propagation lines (SURVEY.md 8f)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
@@ -361,6 +403,8 @@ def run_rank(args) -> int:
             line["host_api"] = {"rows_per_s": round(per / med, 1), "ms_per_call": round(med * 1e3, 3), "rows_per_call": per,
                                 "first_call_ms": round(ts[0] * 1e3, 3),
                                 "what": "Graph.gfpush_omp (gp_gfpush): int64 seeds on the host -> numpy row/col/value filled in place, median of 3 calls after one warm-up"}
+        if world == 1 and not args.no_next_rows:
+            line["next_rows"] = next_rows(graph, packed, per, K, n_nodes, len(indices), dev)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(indptr, indices, all_seeds[args.warmup * S_step:], recipe, args.cpu_budget_s)
             line["cpu_baseline"] = cb

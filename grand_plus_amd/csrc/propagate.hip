@@ -224,13 +224,23 @@ int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim
     // scratch: two ping-pong feature buffers, the row scales, the long-row list (freed before returning
     // control is not possible for an async call, so they are stream-ordered allocations)
     float *xa = nullptr, *xb = nullptr; double* scale = nullptr; int *long_rows = nullptr, *n_long_d = nullptr;
+    // every exit path releases the scratch (stream-ordered frees: safe while the kernels are still queued)
+    struct Scratch {
+        hipStream_t s; void** p[5];
+        ~Scratch() { for (void** q : p) if (*q) (void)hipFreeAsync(*q, s); }
+    } scratch{s, {(void**)&xa, (void**)&xb, (void**)&scale, (void**)&long_rows, (void**)&n_long_d}};
     const int cap_long = 1 << 20;
-    if (!hip_ok(hipMallocAsync((void**)&xa, nf * sizeof(float), s), "hipMallocAsync") ||
-        !hip_ok(hipMallocAsync((void**)&xb, nf * sizeof(float), s), "hipMallocAsync") ||
-        !hip_ok(hipMallocAsync((void**)&scale, (size_t)n * sizeof(double), s), "hipMallocAsync") ||
-        !hip_ok(hipMallocAsync((void**)&long_rows, (size_t)cap_long * sizeof(int), s), "hipMallocAsync") ||
-        !hip_ok(hipMallocAsync((void**)&n_long_d, sizeof(int), s), "hipMallocAsync"))
-        return GP_ERR_NOMEM;
+    auto alloc = [&](void** ptr, size_t bytes) -> int {
+        const hipError_t e = hipMallocAsync(ptr, bytes, s);
+        if (e == hipSuccess) return GP_OK;
+        (void)hipGetLastError();
+        gp_internal_set_error(e == hipErrorOutOfMemory ? GP_ERR_NOMEM : GP_ERR_HIP, "hipMallocAsync", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? GP_ERR_NOMEM : GP_ERR_HIP;
+    };
+    if ((rc = alloc((void**)&xa, nf * sizeof(float))) || (rc = alloc((void**)&xb, nf * sizeof(float))) ||
+        (rc = alloc((void**)&scale, (size_t)n * sizeof(double))) || (rc = alloc((void**)&long_rows, (size_t)cap_long * sizeof(int))) ||
+        (rc = alloc((void**)&n_long_d, sizeof(int))))
+        return rc;
     if (!hip_ok(hipMemsetAsync(n_long_d, 0, sizeof(int), s), "hipMemsetAsync")) return GP_ERR_HIP;
 
     const double numer = mode == 0 ? 1.0 - alpha : 1.0;
@@ -278,9 +288,7 @@ int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim
     if (mode == 1) hipLaunchKernelGGL(scale_kernel, dim3(4096), dim3(256), 0, s, d_out, 1.0f / (float)(order + 1), (long long)nf);   // model.py:201
     if (mode == 2) { if (!hip_ok(hipMemcpyAsync(d_out, cur, nf * sizeof(float), hipMemcpyDeviceToDevice, s), "hipMemcpyAsync")) return GP_ERR_HIP; }
     if (!hip_ok(hipGetLastError(), "propagate kernels")) return GP_ERR_HIP;
-    (void)hipFreeAsync(xa, s); (void)hipFreeAsync(xb, s); (void)hipFreeAsync(scale, s);
-    (void)hipFreeAsync(long_rows, s); (void)hipFreeAsync(n_long_d, s);
-    return GP_OK;
+    return GP_OK;                                          // ~Scratch frees
 }
 
 }  // extern "C"

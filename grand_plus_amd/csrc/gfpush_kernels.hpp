@@ -920,6 +920,40 @@ __device__ __forceinline__ void topk_pick_bin(Ctl* ctl, const u32* hist, u32 wan
     }
 }
 
+// G x 4 consecutive reserve-log records per thread with 16-byte loads (one for the keys, two for the values of a
+// group of four): the passes over the log are cold streaming reads whose cost is round trips, so what counts is bytes in
+// flight per load instruction -- 12 records per thread with 9 loads instead of 8 records with 16.  Thread t of a sweep
+// takes records [base + 4 t, base + 4 t + 4) of every 4*BLOCK-record group; records at or past n_log come back as
+// (kEmpty, 0).  Requires 16-byte aligned log arrays and a capacity that is a multiple of 4 (host: slab_sizes).
+template <int BLOCK, int G>
+__device__ __forceinline__ void load_log_records(const int* log_key, const double* log_val, u32 base, u32 n_log, int tid,
+                                                 int (&k)[4 * G], double (&v)[4 * G])
+{
+    typedef int    i4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    i4 kk[G]; d2 va[G], vb[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const u32 i0 = base + (u32)g * 4u * BLOCK + 4u * (u32)tid;
+        kk[g] = i4{kEmpty, kEmpty, kEmpty, kEmpty}; va[g] = d2{0.0, 0.0}; vb[g] = d2{0.0, 0.0};
+        if (i0 < n_log) {
+            kk[g] = *(const i4*)&log_key[i0]; va[g] = *(const d2*)&log_val[i0]; vb[g] = *(const d2*)&log_val[i0 + 2];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const u32 i0 = base + (u32)g * 4u * BLOCK + 4u * (u32)tid;
+        const int ks[4] = {kk[g].x, kk[g].y, kk[g].z, kk[g].w};
+        const double vs[4] = {va[g].x, va[g].y, vb[g].x, vb[g].y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = i0 + (u32)j < n_log;
+            k[4 * g + j] = valid ? ks[j] : kEmpty;
+            v[4 * g + j] = valid ? vs[j] : 0.0;
+        }
+    }
+}
+
 // RESERVE + TOP-K of one row (graph.h:111-126).  `scratch` is the whole LDS table region:
 //   hist[4096] u32 | sel[K] | tie[kBucketCap] | agg = { vals f64[CA], keys i32[CA] }  (re-used as big[] of Cand)
 // 1. The reserve log is summed per node in the LDS table `agg` (one partition of the keys at
@@ -1028,7 +1062,10 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             GP_SYNC();
             GP_SUB(0);
             bool ok = true;
-            constexpr int UA = 8;                                                 // records in flight per thread
+#ifndef GP_TOPK_UA
+#define GP_TOPK_UA 12
+#endif
+            constexpr int UA = GP_TOPK_UA;                                        // records in flight per thread (groups of 4, 16-byte loads)
             // Pass A: claim.  Only ~10 % of the records reach thr, so claiming them where they stand ran eight
             // probe sequences per step at a few active lanes each.  The wave stages the qualifying keys in its
             // 64-word scratch (ballot + mbcnt positions; LDS operations of one wave execute in order) and claims
@@ -1042,12 +1079,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             };
             for (u32 base = 0; base < n_log; base += UA * BLOCK) {
                 int kk[UA]; double vv[UA];
-#pragma unroll
-                for (int u = 0; u < UA; ++u) {
-                    const u32 i = base + (u32)u * BLOCK + tid;
-                    kk[u] = kEmpty; vv[u] = 0.0;
-                    if (i < n_log) { vv[u] = log_val[i]; kk[u] = log_key[i]; }   // both unconditionally: one latency, not two
-                }
+                load_log_records<BLOCK, UA / 4>(log_key, log_val, base, n_log, tid, kk, vv);   // keys too: one latency, not two
 #pragma unroll
                 for (int u = 0; u < UA; ++u) {
                     const bool q = vv[u] >= thr;
@@ -1065,12 +1097,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
             if (!ctl->ovf) {
                 for (u32 base = 0; base < n_log; base += UA * BLOCK) {           // pass B: add
                     int kk[UA]; double vv[UA];
-#pragma unroll
-                    for (int u = 0; u < UA; ++u) {
-                        const u32 i = base + (u32)u * BLOCK + tid;
-                        kk[u] = kEmpty; vv[u] = 0.0;
-                        if (i < n_log) { kk[u] = log_key[i]; vv[u] = log_val[i]; }
-                    }
+                    load_log_records<BLOCK, UA / 4>(log_key, log_val, base, n_log, tid, kk, vv);
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
                         if (kk[u] == kEmpty) continue;

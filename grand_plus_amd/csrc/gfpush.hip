@@ -117,9 +117,15 @@ struct gp_graph {
 namespace {
 
 template <int BLOCK> int launch_kernel(const KParams& kp, int n_wg, int lds_bytes, hipStream_t s) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gfpush_kernel<BLOCK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL(gfpush_kernel<BLOCK>, dim3(n_wg), dim3(BLOCK), lds_bytes, s, kp);
+    if (kp.row_map) {                                   // the retry launch (its own symbol: see gfpush_retry_kernel)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gfpush_retry_kernel<BLOCK>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(gfpush_retry_kernel<BLOCK>, dim3(n_wg), dim3(BLOCK), lds_bytes, s, kp);
+    } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gfpush_kernel<BLOCK>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(gfpush_kernel<BLOCK>, dim3(n_wg), dim3(BLOCK), lds_bytes, s, kp);
+    }
     HIP_TRY(hipGetLastError());
     return GP_OK;
 }

@@ -1312,7 +1312,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
 #define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
 #endif
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MINW_512 : 4) gfpush_kernel(const KParams p)
+__device__ __forceinline__ void gfpush_rows(const KParams& p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctl* ctl   = (Ctl*)smem;
@@ -1716,6 +1716,19 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MI
         __hip_atomic_fetch_add(&p.counters[kDiagX0 + 2], (u64)ctl->barn[tid >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
+}
+
+// The two launches of a call are separate kernel symbols so that profilers report them separately (the retry launch is a
+// few microseconds of nothing whenever no row outgrew its slab, and would halve the "average gfpush_kernel duration").
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MINW_512 : 4) gfpush_kernel(const KParams p)
+{
+    gfpush_rows<BLOCK>(p);
+}
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MINW_512 : 4) gfpush_retry_kernel(const KParams p)
+{
+    gfpush_rows<BLOCK>(p);
 }
 
 // Fills the per-workgroup HBM residue tables with empty records (a byte memset cannot: val must be 0).

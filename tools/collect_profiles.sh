@@ -6,7 +6,7 @@ TAG=${1:-final}; OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 # 1. kernel trace of the default bench line (MAG shape)
-timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows > $OUT/trace.log 2>&1
 cp $(ls -t $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 # 2. PMC passes
 tools/collect_pmc.sh mag $OUT/pmc
@@ -15,7 +15,7 @@ python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > /dev/null
 python - <<PY
 import json, subprocess, sys
 out = {}
-for w, extra in (("mag", []), ("pubmed", []), ("reddit", []), ("cora", []), ("amazon2m", ["--seeds-per-gpu", "4096"])):
+for w, extra in (("mag", []), ("pubmed", []), ("reddit", []), ("cora", []), ("amazon2m", ["--seeds-per-gpu", "12350"])):
     r = subprocess.run([sys.executable, "bench.py", "--workload", w] + extra, capture_output=True, text=True)
     try:
         out[w] = json.loads(r.stdout.strip().splitlines()[-1])

@@ -113,6 +113,7 @@ struct Ctl {
 #ifdef GP_DIAG
     u64 barw[16];         // per wave: shader cycles spent waiting at workgroup barriers
     u32 barn[16];         // per wave: barriers passed
+    u64 scan_sub[4];      // wave 0: shader cycles in SCAN's (a,b) compaction / (c) records / (d) lookups + push entries / tail
 #endif
 };
 // Statistics live in LDS, not in registers: nine 64-bit per-thread counters alive for the whole kernel
@@ -554,6 +555,9 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
     const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
     const u32 wb = (u32)(tid >> 6) * range;
     u32 tot = 0;
+#ifdef GP_DIAG
+    u64 ss0 = clock64(), ss1 = 0, ss2 = 0, ss3 = 0;
+#endif
     for (u32 sub = wb; sub < wb + range && sub < cap; sub += 256u) {
         // (a) drain 4 adjacent slots per lane
         const u32 s0 = sub + 4u * (u32)lane;
@@ -580,6 +584,9 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         tot += c0 + c1 + c2 + c3;
     }
+#ifdef GP_DIAG
+    ss1 = ss2 = ss3 = clock64();
+#endif
     if (tot != 0) {
         u32 lb = 0;
         if (lane == 0) lb = __hip_atomic_fetch_add(&ctl->log_count, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -619,6 +626,9 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
             }
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#ifdef GP_DIAG
+        ss2 = ss3 = clock64();
+#endif
         // (d) the nodes that may push: V x 64 per step, their indptr loads in flight together
 #ifndef GP_SCAN_V
 #define GP_SCAN_V 2
@@ -686,6 +696,9 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
             }
         }
     }
+#ifdef GP_DIAG
+    if (tot != 0) ss3 = clock64();
+#endif
     // edge totals of the next level and the statistics: one LDS atomic per wave (64 same-address
     // atomics per step would serialise)
     if (lane == 0 && tot) stat_add(ctl, sFront, tot);
@@ -701,6 +714,12 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
             if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
         }
     }
+#ifdef GP_DIAG
+    if (tid == 0) {
+        const u64 ss4 = clock64();
+        ctl->scan_sub[0] += ss1 - ss0; ctl->scan_sub[1] += ss2 - ss1; ctl->scan_sub[2] += ss3 - ss2; ctl->scan_sub[3] += ss4 - ss3;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- EXPAND
@@ -1340,6 +1359,7 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
     u64 gp_sub_t = 0; u64 gp_sub_acc[16];
     for (int i = 0; i < 16; ++i) gp_sub_acc[i] = 0;
     if (tid < 16) { ctl->barw[tid] = 0; ctl->barn[tid] = 0; }
+    if (tid < 4) ctl->scan_sub[tid] = 0;
     const u64 wave_t0 = clock64();
 #endif
     const int L = p.n_coef - 1;
@@ -1714,6 +1734,8 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
         __hip_atomic_fetch_add(&p.counters[kDiagX0 + 0], clock64() - wave_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kDiagX0 + 1], ctl->barw[tid >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&p.counters[kDiagX0 + 2], (u64)ctl->barn[tid >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) for (int i = 0; i < 4; ++i)
+            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 8 + i], ctl->scan_sub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
 }

@@ -36,6 +36,7 @@ def main():
               f"({dx[1] / max(dx[2], 1):.0f} cyc waited per wave per barrier); wave cycles/row {dx[0] / 16 / rows:.0f}", flush=True)
         print(f"   per row (us): prologue {dx[4] / rows / 100:.2f}  level0 {dx[5] / rows / 100:.2f}  level-loop outside expand/scan {dx[6] / rows / 100:.2f}  "
               f"table restore {dx[7] / rows / 100:.2f}  topk {st['diag_ticks_topk'] / rows / 100:.2f}", flush=True)
+        print("   SCAN of wave 0 (cycles/row): compact (a,b) %.0f  records (c) %.0f  lookups+entries (d) %.0f  tail %.0f" % tuple(dx[8 + i] / rows for i in range(4)), flush=True)
         names = ["agg_init", "agg_insert", "agg_scan", "sel_hist", "sel_pick", "sel_compact", "sel_collect", "final"]
         print("   topk sub-phases (us/row):", {n: round(st["diag_sub"][i] / rows / 100, 2) for i, n in enumerate(names)}, flush=True)
         for lvl in range(1, 16):

@@ -62,7 +62,16 @@ constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= 
 constexpr int    kFlatW      = 4;       // EXPAND: 64-edge windows a wave keeps in flight (column loads issued together)
 constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic LDS ...
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (expand_flat)
-constexpr u32    kMinCap     = 1024;    // smallest table capacity used for a level
+#ifndef GP_MIN_CAP
+#define GP_MIN_CAP 1024
+#endif
+#ifndef GP_CAP_MULT
+#define GP_CAP_MULT 4
+#endif
+#ifndef GP_SCAN_VC
+#define GP_SCAN_VC 2
+#endif
+constexpr u32    kMinCap     = GP_MIN_CAP;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
 #ifndef GP_BUCKET_MIN
 #define GP_BUCKET_MIN 3
@@ -596,7 +605,7 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
         //     the slots consumed so far, so that the expensive part -- indptr lookup, fp64 division,
         //     push-list allocation -- runs with full lanes in (d) instead of once per 64 nodes at ~5 lanes.
         u32 ncand = 0;
-        constexpr int VC = 2;
+        constexpr int VC = GP_SCAN_VC;
         for (u32 j = 0; j < tot; j += 64 * VC) {
             int k[VC]; double r[VC]; bool cnd[VC];
 #pragma unroll
@@ -1481,7 +1490,7 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                 cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
             } else if (in_lds) {
                 if (need * 4 <= (u64)C * 3) {
-                    cap = (u32)min((u64)C, max((u64)kMinCap, 4 * need));
+                    cap = (u32)min((u64)C, max((u64)kMinCap, (((u64)GP_CAP_MULT * need) + 3) & ~3ull));
                 } else {
                     // target load of a partition: 0.75 of the table counted in EDGES (distinct targets are ~15 % fewer); a partition
                     // that overflows anyway is split in place.  0.55 -> 0.75 saved half a pass on the peak levels of the 80 KB shape (+2 %).

@@ -74,7 +74,7 @@ constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed 
 constexpr u32    kMinCap     = GP_MIN_CAP;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
 #ifndef GP_BUCKET_MIN
-#define GP_BUCKET_MIN 3
+#define GP_BUCKET_MIN 2
 #endif
 constexpr u32    kBucketMin  = GP_BUCKET_MIN;       // levels needing at least this many partitions bucket their edges in HBM once
                                         // instead of re-reading and hash-filtering every CSR range once per partition
@@ -800,10 +800,11 @@ __device__ __forceinline__ void expand_list(const KParams& p, u32* flag, int* lk
 // edge i is entry `first + popcount(M & lanes <= i)` -- mbcnt, no search.  The owner's (start - prefix, share)
 // are then pulled with ds_bpermute.  kFlatW windows are handled per step so that their column loads are in
 // flight together.
-template <int BLOCK, bool IN_LDS, bool DIRECT>
-__device__ __forceinline__ void expand_flat(const KParams& p, u32* flag, unsigned char* wscr, int* lkeys, double* lvals, ResRec* resg, u32 cap,
-                                            const PushEntry* list, long long stride_sign, u32 n_entries,
-                                            u32 part, u32 parts, bool dry = false)
+// The edge enumeration of expand_flat, shared with the SCATTER of bucketed levels: calls f(v, share) with kFlatW
+// 64-edge windows per step (v[w] < 0 marks a lane past the end of the batch).
+template <int BLOCK, class F>
+__device__ __forceinline__ void flat_edges(const KParams& p, unsigned char* wscr, const PushEntry* list, long long stride_sign,
+                                           u32 n_entries, bool dry, F f)
 {
     const int lane = threadIdx.x & 63;
     constexpr u32 kWaves = BLOCK / 64;
@@ -837,19 +838,30 @@ __device__ __forceinline__ void expand_flat(const KParams& p, u32* flag, unsigne
                 const u32 q = t + 64u * (u32)w + (u32)lane;
                 v[w] = q < T ? p.indices[rel_e + (int)q] : -1;                      // graph.h:97
             }
-#ifdef GP_DIAG
-            if (dry && (p.diag_flags & 8)) {                 // timing attribution: the dry pass loads but does not insert
-#pragma unroll
-                for (int w = 0; w < W; ++w) if (v[w] == 0x7FFFFFFF) *flag = 1u;
-                continue;
-            }
-#endif
-#pragma unroll
-            for (int w = 0; w < W; ++w)
-                if (v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part))
-                    res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v[w], sh[w], flag);   // graph.h:98
+            f(v, sh);
         }
     }
+}
+
+template <int BLOCK, bool IN_LDS, bool DIRECT>
+__device__ __forceinline__ void expand_flat(const KParams& p, u32* flag, unsigned char* wscr, int* lkeys, double* lvals, ResRec* resg, u32 cap,
+                                            const PushEntry* list, long long stride_sign, u32 n_entries,
+                                            u32 part, u32 parts, bool dry = false)
+{
+    constexpr int W = kFlatW;
+    flat_edges<BLOCK>(p, wscr, list, stride_sign, n_entries, dry, [&](const int (&v)[W], const double (&sh)[W]) {
+#ifdef GP_DIAG
+        if (dry && (p.diag_flags & 8)) {                     // timing attribution: the dry pass loads but does not insert
+#pragma unroll
+            for (int w = 0; w < W; ++w) if (v[w] == 0x7FFFFFFF) *flag = 1u;
+            return;
+        }
+#endif
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            if (v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part))
+                res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v[w], sh[w], flag);   // graph.h:98
+    });
 }
 
 template <int BLOCK, bool IN_LDS, bool DIRECT = false>
@@ -1540,12 +1552,30 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                 if (tid == 0) ctl->bovf = 0;
                 GP_SYNC();
                 GP_STAMP(t0);
+#ifdef GP_SCATTER_GROUPS
                 for_each_edge<BLOCK>(p, push_cur, n_push_cur, n_long_cur, log2g, [&](int v, double share) {
                     const u32 bk = slot_of(hash_b((u32)v), P);
                     const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (i < stride) { ResRec r; r.key = v; r.pad = 0; r.val = share; bucket[(u64)bk * stride + i] = r; }
                     else ctl->bovf = 1;
                 });
+#else
+                {   // one lane per edge, like EXPAND
+                    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * (threadIdx.x >> 6);
+                    auto scatter = [&](const int (&v)[kFlatW], const double (&sh)[kFlatW]) {
+#pragma unroll
+                        for (int w = 0; w < kFlatW; ++w) {
+                            if (v[w] < 0) continue;
+                            const u32 bk = slot_of(hash_b((u32)v[w]), P);
+                            const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (i < stride) { ResRec r; r.key = v[w]; r.pad = 0; r.val = sh[w]; bucket[(u64)bk * stride + i] = r; }
+                            else ctl->bovf = 1;
+                        }
+                    };
+                    if (n_long_cur) flat_edges<BLOCK>(p, wscr, push_cur + (p.push_cap - 1), -1, n_long_cur, false, scatter);
+                    if (n_push_cur) flat_edges<BLOCK>(p, wscr, push_cur, 1, n_push_cur, false, scatter);
+                }
+#endif
                 GP_SYNC();
                 GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
                 if (ctl->bovf) use_buckets = false;

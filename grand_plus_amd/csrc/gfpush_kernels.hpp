@@ -74,7 +74,7 @@ constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed 
 constexpr u32    kMinCap     = GP_MIN_CAP;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
 #ifndef GP_BUCKET_MIN
-#define GP_BUCKET_MIN 2
+#define GP_BUCKET_MIN 3
 #endif
 constexpr u32    kBucketMin  = GP_BUCKET_MIN;       // levels needing at least this many partitions bucket their edges in HBM once
                                         // instead of re-reading and hash-filtering every CSR range once per partition

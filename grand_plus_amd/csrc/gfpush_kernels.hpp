@@ -1,11 +1,11 @@
 // gfpush_kernels.hpp -- hand-written HIP (gfx950 / CDNA4) kernels for GFPush.
 //
-// One persistent workgroup (16 wave64 by default) owns one seed ("row") at a time and pulls
+// One persistent workgroup (8 or 16 wave64; two or one per CU) owns one seed ("row") at a time and pulls
 // rows from a device-side queue (the reference's `omp parallel for schedule(dynamic)` over
 // seeds, precompute/graph.h:73-74).  Per row it runs the level-synchronous push of
 // graph.h:83-110 and the top-K of graph.h:111-126:
 //
-//   EXPAND  stream the CSR neighbour ranges of the push list (coalesced within a range)
+//   EXPAND  stream the CSR neighbour ranges of the push list, one lane per edge (flat_edges),
 //           and add r/deg into the level's residue table          (graph.h:96-99).
 //   SCAN    drain that table; for every node u with residue r:
 //             reserve[u] += coef[lvl] * r   -> one (u, coef*r) record in the reserve LOG   (graph.h:90 / :109)
@@ -732,14 +732,9 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
 }
 
 // ---------------------------------------------------------------- EXPAND
-// Adds `share` into the next residue table for every column id of every push-list entry
-// (graph.h:96-99).  Long entries (chunks of hub ranges) take a whole wave each; short entries
-// take G lanes (a power of two, 4..64 ~ their mean length).  Groups stride over the list so
-// every wave has work even when the list is short, and each group keeps B entries in flight:
-// the B entry loads are issued together, then the 2*B column loads, then the table updates
-// -- two exposed memory latencies per B entries instead of two per entry.
-// With parts > 1 only targets of hash partition `part` are kept (the others belong to a
-// later pass over the same list).
+// Adds `share` into the next residue table for every column id of every push-list entry (graph.h:96-99): flat_edges
+// enumerates the edges one lane per edge, expand_flat inserts them.  With parts > 1 only targets of hash partition
+// `part` are kept (the others belong to a later pass over the same list).
 template <bool IN_LDS, bool DIRECT>
 __device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* resg, u32 cap, u32 node_mask, int v, double share, u32* flag) {
     if (DIRECT) { res_add_direct(lkeys, lvals, node_mask, v, share); return; }
@@ -747,53 +742,10 @@ __device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* r
     else if (!res_add_hbm(resg, cap, v, share)) *flag = 1u;
 }
 
-template <int BLOCK, bool IN_LDS, int B, bool DIRECT>
-__device__ __forceinline__ void expand_list(const KParams& p, u32* flag, int* lkeys, double* lvals, ResRec* resg, u32 cap,
-                                            const PushEntry* list, long long stride_sign, u32 n_entries,
-                                            int log2g, u32 part, u32 parts, bool dry = false)
-{
-    const int tid = threadIdx.x;
-    const int G = 1 << log2g;
-    const int gl = tid & (G - 1);
-    const u32 gid = (u32)tid >> log2g;
-    const u32 n_groups = (u32)BLOCK >> log2g;
-    for (u32 e0 = gid; e0 < n_entries; e0 += n_groups * B) {
-        PushEntry pe[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-            const u32 e = e0 + (u32)b * n_groups;
-            pe[b].start = 0; pe[b].len = 0; pe[b].share = 0.0;
-            if (e < n_entries) pe[b] = list[stride_sign * (long long)e];
-            if (dry) pe[b].share = 0.0;          // GP_DIAG: a second, value-neutral pass (instruction attribution)
-        }
-        int v0[B], v1[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-            v0[b] = gl < pe[b].len ? p.indices[pe[b].start + gl] : -1;                  // graph.h:97
-            v1[b] = gl + G < pe[b].len ? p.indices[pe[b].start + gl + G] : -1;
-        }
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-            if (v0[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v0[b]), parts) == part))
-                res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v0[b], pe[b].share, flag);   // graph.h:98
-            if (v1[b] >= 0 && (parts == 1 || slot_of(hash_b((u32)v1[b]), parts) == part))
-                res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v1[b], pe[b].share, flag);
-        }
-#pragma unroll
-        for (int b = 0; b < B; ++b) {                       // tails of entries longer than 2*G
-            for (int j = gl + 2 * G; j < pe[b].len; j += G) {
-                const int v = p.indices[pe[b].start + j];
-                if (parts == 1 || slot_of(hash_b((u32)v), parts) == part)
-                    res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v, pe[b].share, flag);
-            }
-        }
-    }
-}
-
 // EXPAND, flattened: ONE LANE PER EDGE.  A wave takes a batch of up to 64 consecutive push-list entries (lane j
 // owns entry j), prefix-sums their lengths, and walks the batch's T edges in windows of 64: lane i of a window
 // handles edge q = t + i, whatever entry it belongs to.  So every column load and every table insert runs with
-// all 64 lanes busy (the per-entry lane groups of expand_list sat at ~45 % because range lengths vary 1..32):
+// all 64 lanes busy (the per-entry lane groups of round 1 sat at ~45 % because range lengths vary 1..32):
 // ~2.4x fewer wave-instructions per edge in a phase that is instruction-issue bound while it runs.
 // Edge -> entry: the entries starting inside the window flag their first edge in a per-wave byte array (LDS
 // operations of one wave execute in order: no barrier), a ballot turns the flags into a mask M, and the owner of
@@ -867,43 +819,20 @@ __device__ __forceinline__ void expand_flat(const KParams& p, u32* flag, unsigne
 template <int BLOCK, bool IN_LDS, bool DIRECT = false>
 __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
                                              ResRec* resg, u32 cap, const PushEntry* push,
-                                             u32 n_short, u32 n_long, int log2g, u32 part, u32 parts, bool dry = false)
+                                             u32 n_short, u32 n_long, u32 part, u32 parts, bool dry = false)
 {
     u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
-#ifdef GP_EXPAND_GROUPS
-    if (n_long)  expand_list<BLOCK, IN_LDS, 2, DIRECT>(p, flag, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, 6, part, parts, dry);
-    if (n_short) expand_list<BLOCK, IN_LDS, 4, DIRECT>(p, flag, lkeys, lvals, resg, cap, push, 1, n_short, log2g, part, parts, dry);
-#else
     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * (threadIdx.x >> 6);
+    // hub chunks (<= kSplitLen columns each) grow from the back of the push buffer, the other ranges from its front
     if (n_long)  expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, part, parts, dry);
     if (n_short) expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push, 1, n_short, part, parts, dry);
-#endif
 }
 
 // ---------------------------------------------------------------- bucketed levels
-// A level that needs many LDS partitions (Amazon2M-shape at rmax 1e-6: ~100 k edges, ~14 partitions)
-// would re-read and hash-filter every CSR range once per partition.  Instead its edges are visited
-// three times in total: COUNT per bucket, SCATTER (key, share) records into per-bucket runs of an HBM
-// buffer, then one clean insert pass per bucket with every lane busy.
-template <int BLOCK, class F>
-__device__ __forceinline__ void for_each_edge(const KParams& p, const PushEntry* push, u32 n_short, u32 n_long, int log2g, F f)
-{
-    const int tid = threadIdx.x;
-    {   // long entries: a whole wave per entry
-        const int gl = tid & 63; const u32 gid = (u32)tid >> 6, n_groups = (u32)BLOCK >> 6;
-        for (u32 e = gid; e < n_long; e += n_groups) {
-            const PushEntry pe = push[(long long)p.push_cap - 1 - (long long)e];
-            for (int j = gl; j < pe.len; j += 64) f(p.indices[pe.start + j], pe.share);
-        }
-    }
-    {   // short entries: G lanes per entry
-        const int G = 1 << log2g, gl = tid & (G - 1); const u32 gid = (u32)tid >> log2g, n_groups = (u32)BLOCK >> log2g;
-        for (u32 e = gid; e < n_short; e += n_groups) {
-            const PushEntry pe = push[e];
-            for (int j = gl; j < pe.len; j += G) f(p.indices[pe.start + j], pe.share);
-        }
-    }
-}
+// A level that needs several LDS partitions (Amazon2M-shape at rmax 1e-6: ~100 k edges, ~14 partitions) would re-read and
+// hash-filter every CSR range once per partition.  Instead its edges are visited twice: SCATTER (key, share) records into
+// fixed-stride per-bucket runs of an HBM buffer (flat_edges: one lane per edge), then one clean insert pass per bucket with
+// every lane busy (the level loop of gfpush_rows).
 
 // ---------------------------------------------------------------- TOP-K
 // Candidates are ordered by the 96-bit composite (value bits, ~column): larger composite =
@@ -1511,8 +1440,6 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                     if (parts > kMaxParts) in_lds = false;
                 }
             }
-            int log2g = 2;                               // lanes per entry ~ mean range length
-            if (n_push_cur) { const u32 avg = e_short_cur / n_push_cur; while (log2g < 6 && (1u << log2g) < avg) ++log2g; }
             PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
             PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
             const u32 snap_log = ctl->log_count;          // first log record of this level
@@ -1552,14 +1479,6 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                 if (tid == 0) ctl->bovf = 0;
                 GP_SYNC();
                 GP_STAMP(t0);
-#ifdef GP_SCATTER_GROUPS
-                for_each_edge<BLOCK>(p, push_cur, n_push_cur, n_long_cur, log2g, [&](int v, double share) {
-                    const u32 bk = slot_of(hash_b((u32)v), P);
-                    const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (i < stride) { ResRec r; r.key = v; r.pad = 0; r.val = share; bucket[(u64)bk * stride + i] = r; }
-                    else ctl->bovf = 1;
-                });
-#else
                 {   // one lane per edge, like EXPAND
                     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * (threadIdx.x >> 6);
                     auto scatter = [&](const int (&v)[kFlatW], const double (&sh)[kFlatW]) {
@@ -1575,7 +1494,6 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                     if (n_long_cur) flat_edges<BLOCK>(p, wscr, push_cur + (p.push_cap - 1), -1, n_long_cur, false, scatter);
                     if (n_push_cur) flat_edges<BLOCK>(p, wscr, push_cur, 1, n_push_cur, false, scatter);
                 }
-#endif
                 GP_SYNC();
                 GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
                 if (ctl->bovf) use_buckets = false;
@@ -1639,13 +1557,13 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
 #endif
                         {
                             if (BLOCK == 512 && direct) {
-                                expand_level<BLOCK, true, BLOCK == 512>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
+                                expand_level<BLOCK, true, BLOCK == 512>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np);
                                 if (tid == 0 && has_dang_cur) res_add_direct(lkeys, lvals, p.node_mask, seed_key, dang_cur);       // graph.h:92
                             } else {
-                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
-                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np);
+                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np);
+                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np);
 #ifdef GP_DIAG
-                            if ((p.diag_flags & 2) && in_lds) expand_level<BLOCK, true>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, log2g, part, np, true);
+                            if ((p.diag_flags & 2) && in_lds) expand_level<BLOCK, true>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np, true);
 #endif
                             if (tid == 0 && has_dang_cur &&
                                 (np == 1 || slot_of(hash_b((u32)seed_key), np) == part)) {          // graph.h:92

@@ -180,8 +180,8 @@ class Graph:
 
     def diag_counters(self):
         """Extended counters of the diagnostic build (GRANDPLUS_DIAG=1); zeros in the product library."""
-        buf = (ctypes.c_int64 * 128)()
-        _native.raise_for_status(_native.lib().gp_internal_diag_counters(self._h, buf, 128))
+        buf = (ctypes.c_int64 * 256)()
+        _native.raise_for_status(_native.lib().gp_internal_diag_counters(self._h, buf, 256))
         return list(buf)
 
     def set_option(self, key: str, value: int):

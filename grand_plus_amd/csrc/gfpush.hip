@@ -352,7 +352,7 @@ int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indic
 int gp_internal_diag_counters(gp_graph* g, int64_t* out, int n) {
     if (!g || !out) return fail(GP_ERR_NULL, "null argument");
     if (g->launched) { HIP_TRY(hipSetDevice(g->device)); HIP_TRY(hipStreamSynchronize(g->last_stream)); }
-    for (int i = 0; i < n; ++i) out[i] = i < 128 && g->launched ? (int64_t)g->h_counters[kDiagX0 + i] : 0;
+    for (int i = 0; i < n; ++i) out[i] = i < 256 && g->launched ? (int64_t)g->h_counters[kDiagX0 + i] : 0;
     return GP_OK;
 }
 

@@ -59,8 +59,15 @@ constexpr int    kSplitLen   = 128;     // a long CSR range is split into chunks
 constexpr int    kLongLen    = 64;      // upper limit of KParams::long_len (ranges longer than long_len are expanded by a whole wave)
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
-constexpr int    kFlatW      = 4;       // EXPAND: 64-edge windows a wave keeps in flight (column loads issued together)
+#ifndef GP_FLAT_W
+#define GP_FLAT_W 4
+#endif
+constexpr int    kFlatW      = GP_FLAT_W;       // EXPAND: 64-edge windows a wave keeps in flight (column loads issued together)
+#ifdef GP_DIAG
+constexpr int    kCtlStruct  = 2048;    // (diagnostic build: + per-barrier-site wait counters)
+#else
 constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic LDS ...
+#endif
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (expand_flat)
 #ifndef GP_MIN_CAP
 #define GP_MIN_CAP 1024
@@ -123,6 +130,8 @@ struct Ctl {
     u64 barw[16];         // per wave: shader cycles spent waiting at workgroup barriers
     u32 barn[16];         // per wave: barriers passed
     u64 scan_sub[4];      // wave 0: shader cycles in SCAN's (a,b) compaction / (c) records / (d) lookups + push entries / tail
+    u64 site_w[64];       // per GP_SYNC() site (in source order): shader cycles all waves waited there
+    u32 site_n[64];       // per site: wave arrivals
 #endif
 };
 // Statistics live in LDS, not in registers: nine 64-bit per-thread counters alive for the whole kernel
@@ -157,7 +166,7 @@ enum Counter { kQueue = 0, kQueueRetry, kRetryRows,          // zeroed at every 
                kGlobalLevels, kFailedRows, kDegLookups,
                kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
                kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
-               kDiagX0, kDiagXLast = kDiagX0 + 127,   // GP_DIAG: [0] wave cycles, [1] cycles waves spent at barriers, [2] barriers; [16 + 6*lvl + k] per level:
+               kDiagX0, kDiagXLast = kDiagX0 + 255,   // GP_DIAG: [0] wave cycles, [1] cycles waves spent at barriers, [2] barriers; [16 + 6*lvl + k] per level:
                                                     //   k = 0 expand ticks, 1 scan ticks, 2 edges, 3 frontier nodes, 4 push entries, 5 table passes
                kNumCounters };
 
@@ -165,7 +174,9 @@ enum Counter { kQueue = 0, kQueueRetry, kRetryRows,          // zeroed at every 
 // 100 MHz clock at phase boundaries.  The product build compiles them to nothing.
 // Workgroup barrier.  The diagnostic build measures what the waves spend waiting at it (shader cycles).
 #ifdef GP_DIAG
-#define GP_SYNC() do { const u64 tb_ = clock64(); __syncthreads(); if ((threadIdx.x & 63) == 0) { ctl->barw[threadIdx.x >> 6] += clock64() - tb_; ++ctl->barn[threadIdx.x >> 6]; } } while (0)
+constexpr int kSyncBase = __COUNTER__;
+#define GP_SYNC() do { constexpr int site_ = (__COUNTER__ - kSyncBase - 1) & 63; const u64 tb_ = clock64(); __syncthreads(); if ((threadIdx.x & 63) == 0) { const u64 w_ = clock64() - tb_; ctl->barw[threadIdx.x >> 6] += w_; ++ctl->barn[threadIdx.x >> 6]; \
+    __hip_atomic_fetch_add(&ctl->site_w[site_], w_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&ctl->site_n[site_], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } } while (0)
 #else
 #define GP_SYNC() __syncthreads()
 #endif
@@ -232,7 +243,7 @@ __device__ __forceinline__ u32 slot_of(u32 h, u32 cap) { return (u32)(((u64)h * 
 // Home slot in an LDS table of `cap` slots.  Homes lie in [0, cap - kProbeSpan): a probe sequence then
 // never leaves [0, cap), so the probing loops need no wrap-around (4 VALU per probe); 2 % of a full
 // table is the price.  Every LDS table has cap >= kMinCap > kProbeSpan.
-static_assert(kFlatW == 4, "expand_flat clears its flags with one 32-bit store per lane");
+static_assert(kFlatW == 4 || kFlatW == 8, "expand_flat clears its flags with one 32- or 64-bit store per lane");
 static_assert(kMinCap > 2 * kProbeSpan, "every LDS table must be much larger than the probe span");
 __device__ __forceinline__ u32 home_lds(u32 k, u32 cap) { return slot_of(hash_a(k), cap - kProbeSpan); }
 
@@ -775,7 +786,8 @@ __device__ __forceinline__ void flat_edges(const KParams& p, unsigned char* wscr
         const u32 T = (u32)__builtin_amdgcn_readlane((int)incl, 63);     // edges of the batch
         const int rel = start - (int)excl;                               // column index of edge q = rel(owner) + q   graph.h:97
         for (u32 t = 0; t < T; t += 64u * W) {
-            *(u32*)(wscr + 4 * lane) = 0u;                               // clears the 64*W flags (W == 4)
+            if (W == 4) *(u32*)(wscr + 4 * lane) = 0u;                   // clears the 64*W flags
+            else        *(u64*)(wscr + 8 * lane) = 0ull;
             if (len != 0 && excl > t && excl < t + 64u * W) wscr[excl - t] = 1;
             u32 before = (u32)__popcll(__ballot(len != 0 && excl <= t)) - 1u;    // owner of edge t (wave-uniform)
             int v[W]; double sh[W];
@@ -1280,6 +1292,12 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
 #ifndef GP_MINW_512
 #define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
 #endif
+#ifndef GP_MINW_768
+#define GP_MINW_768 3
+#endif
+#ifndef GP_MINW_1024
+#define GP_MINW_1024 4         // 8: two 1024-thread workgroups per CU with 64 VGPRs (tools/ab.sh experiments)
+#endif
 template <int BLOCK>
 __device__ __forceinline__ void gfpush_rows(const KParams& p)
 {
@@ -1310,6 +1328,7 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
     for (int i = 0; i < 16; ++i) gp_sub_acc[i] = 0;
     if (tid < 16) { ctl->barw[tid] = 0; ctl->barn[tid] = 0; }
     if (tid < 4) ctl->scan_sub[tid] = 0;
+    if (tid < 64) { ctl->site_w[tid] = 0; ctl->site_n[tid] = 0; }
     const u64 wave_t0 = clock64();
 #endif
     const int L = p.n_coef - 1;
@@ -1694,18 +1713,23 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
         if (tid == 0) for (int i = 0; i < 4; ++i)
             __hip_atomic_fetch_add(&p.counters[kDiagX0 + 8 + i], ctl->scan_sub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (tid < 64 && ctl->site_n[tid]) {       // [128 + site] cycles waited at GP_SYNC() number `site` (source order), [192 + site] wave arrivals
+        __hip_atomic_fetch_add(&p.counters[kDiagX0 + 128 + tid], ctl->site_w[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.counters[kDiagX0 + 192 + tid], (u64)ctl->site_n[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #endif
 }
 
 // The two launches of a call are separate kernel symbols so that profilers report them separately (the retry launch is a
 // few microseconds of nothing whenever no row outgrew its slab, and would halve the "average gfpush_kernel duration").
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MINW_512 : 4) gfpush_kernel(const KParams p)
+__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? GP_MINW_768 : BLOCK == 512 ? GP_MINW_512 : BLOCK == 1024 ? GP_MINW_1024 : 4) gfpush_kernel(const KParams p)
 {
     gfpush_rows<BLOCK>(p);
 }
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? 3 : BLOCK == 512 ? GP_MINW_512 : 4) gfpush_retry_kernel(const KParams p)
+__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? GP_MINW_768 : BLOCK == 512 ? GP_MINW_512 : BLOCK == 1024 ? GP_MINW_1024 : 4) gfpush_retry_kernel(const KParams p)
 {
     gfpush_rows<BLOCK>(p);
 }

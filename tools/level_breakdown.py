@@ -39,6 +39,15 @@ def main():
         print("   SCAN of wave 0 (cycles/row): compact (a,b) %.0f  records (c) %.0f  lookups+entries (d) %.0f  tail %.0f" % tuple(dx[8 + i] / rows for i in range(4)), flush=True)
         names = ["agg_init", "agg_insert", "agg_scan", "sel_hist", "sel_pick", "sel_compact", "sel_collect", "final"]
         print("   topk sub-phases (us/row):", {n: round(st["diag_sub"][i] / rows / 100, 2) for i, n in enumerate(names)}, flush=True)
+        if os.environ.get("GP_SITES"):
+            # barrier sites in source order: GP_SYNC() occurrences after the macro definitions
+            src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "grand_plus_amd", "csrc", "gfpush_kernels.hpp")).read().split("\n")
+            lines = [i + 1 for i, l in enumerate(src) if "GP_SYNC();" in l and "#define" not in l]
+            tot_w = sum(dx[128:192])
+            print("   barrier sites (line: waited us/row/wave, arrivals/row/wave, share of all barrier wait):")
+            for site in range(64):
+                if dx[192 + site]:
+                    print(f"     {lines[site] if site < len(lines) else '?':>5}: {dx[128 + site] / rows / 8 / 2400:7.2f} us  {dx[192 + site] / rows / 8:6.2f}  {dx[128 + site] / max(tot_w, 1):.3f}   {src[lines[site] - 1].strip()[:60] if site < len(lines) else ''}")
         for lvl in range(1, 16):
             e, s, ed, nd, pe, ps = dx[16 + 6 * lvl:16 + 6 * lvl + 6]
             if ps == 0:

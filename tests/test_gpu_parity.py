@@ -252,7 +252,7 @@ def test_reddit_shape_properties():
     from grand_plus_amd.recipes import RECIPES
     indptr, indices = synth.shape_csr("reddit")
     n = len(indptr) - 1
-    S = 4096
+    S = 65536                                                         # the row count bench.py times
     seeds = synth.seeds(n, S)
     r = RECIPES[("reddit", "avg")]
     K = r.top_k
@@ -267,7 +267,7 @@ def test_reddit_shape_properties():
         assert len(set(col[it, :f].tolist())) == f
     assert (val.sum(1) <= 1.0 + 1e-12).all()                          # mass is never created
     assert st["edges"] >= st["pushes"] > 0 and st["failed_rows"] == 0
-    sub = np.arange(0, S, 16)
+    sub = np.arange(0, S, 16)                                         # 4 096 rows against the oracle
     exp, _ = _oracle(indptr, indices, seeds[sub], r.coef(), r.rmax, K)
     sel = (got[0].reshape(S, K)[sub].reshape(-1), got[1].reshape(S, K)[sub].reshape(-1), got[2].reshape(S, K)[sub].reshape(-1))
     _assert_parity(seeds[sub], K, sel, exp)
@@ -314,10 +314,10 @@ def test_dangling_nodes_with_packed_degrees():
     assert ost["dangling"] > 0 and st["pushes"] == ost["pushes"]
 
 
-@pytest.mark.parametrize("shape,recipe,S,n_check", [("mag", ("mag", "ppr"), 4096, 64), ("amazon2m", ("amazon2m", "ppr"), 768, 24)])
+@pytest.mark.parametrize("shape,recipe,S,n_check", [("mag", ("mag", "ppr"), 65536, 16384), ("amazon2m", ("amazon2m", "ppr"), 12350, 2048)])
 def test_full_scale_shapes(shape, recipe, S, n_check):
-    """BASELINE configs C5 / C4 at their full graph sizes (12.4 M / 173 M and 2.45 M / 61 M): properties that
-    need no oracle on every row, oracle parity on a sample.  Amazon2M-shape at rmax 1e-6 runs its big levels
+    """BASELINE configs C5 / C4 at their full graph sizes (12.4 M / 173 M and 2.45 M / 61 M) and the row counts bench.py
+    times (65 536 / 12 350): properties that need no oracle on every row, oracle parity on a sample of 16 384 / 2 048 rows.  Amazon2M-shape at rmax 1e-6 runs its big levels
     through the bucketed-level path (~14 buckets)."""
     from grand_plus_amd import synth
     from grand_plus_amd.recipes import RECIPES

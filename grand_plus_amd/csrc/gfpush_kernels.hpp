@@ -321,8 +321,71 @@ __device__ __forceinline__ void wave_alloc_flags(u32* lds_counter, const bool (&
 // another key (walk on, triangular steps).  No pre-read, no nested branches: the loop body is
 // a handful of instructions, which matters because this path is instruction-issue bound.
 // Keys never revert to EMPTY while inserts are running, so a key ends up in exactly one slot.
+#ifndef GP_ASM_PROBE
+#define GP_ASM_PROBE 1
+#endif
+// The probing loops in gfx950 assembly.  The structurizer turns the C++ loops below into 17-26 instructions per probe
+// (nested exec-mask save/restore blocks, boolean results moved through VGPRs); written by hand a probe is the address,
+// the LDS operation, its wait, two v_cmpx that narrow EXEC to the lanes that must walk on, and the scalar step
+// bookkeeping: 9-10 instructions.  All three leave `slot` at the last slot a lane looked at and return the key it saw
+// there (its own key or kEmpty = done, anything else = the probe limit was reached).
+__device__ __forceinline__ u32 lds_addr(const void* p) {          // byte address inside LDS of a pointer known to point there
+    return (u32)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ int probe_cas_asm(int* keys, u32& slot, int k) {
+    int seen; u32 ad; u64 sv; u32 st;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "1:\n\t"
+        "v_lshl_add_u32 %[ad], %[sl], 2, %[base]\n\t"
+        "ds_cmpst_rtn_b32 %[seen], %[ad], %[emp], %[key]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmpx_ne_u32 vcc, %[seen], %[key]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[seen]\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[sl], %[st], %[sl]\n\t"
+        "s_add_u32 %[st], %[st], 1\n\t"
+        "s_cmp_le_u32 %[st], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sl] "+v"(slot), [seen] "=&v"(seen), [ad] "=&v"(ad), [sv] "=&s"(sv), [st] "=&s"(st)
+        : [key] "v"(k), [emp] "v"(kEmpty), [base] "s"(lds_addr(keys)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
+    return seen;
+}
+__device__ __forceinline__ int probe_find_asm(const int* keys, u32& slot, int k) {
+    int seen; u32 ad; u64 sv; u32 st;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "1:\n\t"
+        "v_lshl_add_u32 %[ad], %[sl], 2, %[base]\n\t"
+        "ds_read_b32 %[seen], %[ad]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmpx_ne_u32 vcc, %[seen], %[key]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[seen]\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[sl], %[st], %[sl]\n\t"
+        "s_add_u32 %[st], %[st], 1\n\t"
+        "s_cmp_le_u32 %[st], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sl] "+v"(slot), [seen] "=&v"(seen), [ad] "=&v"(ad), [sv] "=&s"(sv), [st] "=&s"(st)
+        : [key] "v"(k), [base] "s"(lds_addr(keys)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
+    return seen;
+}
 __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {
     u32 slot = home_lds((u32)k, cap);
+#if GP_ASM_PROBE
+    const int seen = probe_cas_asm(keys, slot, k);
+    if (seen != kEmpty && seen != k) return false;
+    __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
+#else
     // A lane leaves the loop as soon as its compare-and-swap hit; `step` is wave-uniform, so the
     // give-up test is scalar, and failure is encoded in `slot` instead of a second flag.
 #pragma unroll 1
@@ -337,12 +400,18 @@ __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, in
     if (slot == 0xFFFFFFFFu) return false;
     __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return true;
+#endif
 }
 
 // Same insert, reporting failure through a sticky LDS flag instead of a return value: the callers that
 // insert eight keys per step would otherwise fold eight results into a lane mask (4 SALU each).
 __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 cap, int k, double v, u32* flag) {
     u32 slot = home_lds((u32)k, cap);
+#if GP_ASM_PROBE
+    const int seen = probe_cas_asm(keys, slot, k);
+    if (seen != kEmpty && seen != k) *flag = 1u;
+    else __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
 #pragma unroll 1
     for (u32 step = 1;; ++step) {
         int seen = kEmpty;
@@ -354,6 +423,7 @@ __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 ca
     }
     if (slot == 0xFFFFFFFFu) *flag = 1u;
     else __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 
 // Direct-indexed table for graphs with N <= slots (Cora, Citeseer): the slot IS the node id, so an insert
@@ -370,6 +440,10 @@ __device__ __forceinline__ bool res_add_direct(int* keys, double* vals, u32 node
 // Claim a slot for k without touching its value (same probe sequence as res_add_lds).
 __device__ __forceinline__ bool lds_claim(int* keys, u32 cap, int k) {
     u32 slot = home_lds((u32)k, cap);
+#if GP_ASM_PROBE
+    const int seen_a = probe_cas_asm(keys, slot, k);
+    return seen_a == kEmpty || seen_a == k;
+#else
 #pragma unroll 1
     for (u32 step = 1; step <= kMaxProbe; ++step) {
         int seen = kEmpty;
@@ -379,10 +453,14 @@ __device__ __forceinline__ bool lds_claim(int* keys, u32 cap, int k) {
         slot += step;                               // stays below cap, see home_lds
     }
     return false;
+#endif
 }
 // Read-only lookup (no inserts may run concurrently): slot of k, or -1.
 __device__ __forceinline__ int lds_find(const int* keys, u32 cap, int k) {
     u32 slot = home_lds((u32)k, cap);
+#if GP_ASM_PROBE
+    return probe_find_asm(keys, slot, k) == k ? (int)slot : -1;
+#else
 #pragma unroll 1
     for (u32 step = 1; step <= kMaxProbe; ++step) {
         const int seen = keys[slot];
@@ -391,6 +469,7 @@ __device__ __forceinline__ int lds_find(const int* keys, u32 cap, int k) {
         slot += step;                               // stays below cap, see home_lds
     }
     return -1;
+#endif
 }
 
 __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double v) {

@@ -155,6 +155,10 @@ __device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x) {
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
     return x;
 }
+// Index of this wave inside its workgroup, as a SCALAR.  threadIdx.x >> 6 is the same in all 64 lanes, but the compiler's
+// divergence analysis cannot know that: loops and branches on values derived from it became exec-mask loops with their
+// counters in vector registers.  readfirstlane states the uniformity.
+__device__ __forceinline__ u32 wave_id() { return (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ u32 wave_sum32(u32 x) {           // sum over the wave, valid in every lane (all 64 lanes must call)
     return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63);
 }
@@ -505,7 +509,7 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr*
 {
     const int tid = threadIdx.x, lane = tid & 63;
     u32 st_push = 0, st_edges = 0, st_front = 0, st_deg = 0;        // this thread, this level
-    const u32 wave_first = (u32)(tid & ~63);
+    const u32 wave_first = wave_id() * 64u;
     for (u32 base = 0; base < cap; base += BLOCK * U) {
         if (base + wave_first >= cap) break;            // wave-uniform: nothing left for this wave
         int k[U]; double r[U]; bool occ[U];
@@ -652,7 +656,7 @@ __device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, Lev
     // wave ceil(nodes / (64 V)) such waits -- not one or two per 256 slots as when (a)-(c) alternated.
     constexpr u32 kWaves = BLOCK / 64;
     const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
-    const u32 wb = (u32)(tid >> 6) * range;
+    const u32 wb = wave_id() * range;
     u32 tot = 0;
 #ifdef GP_DIAG
     u64 ss0 = clock64(), ss1 = 0, ss2 = 0, ss3 = 0;
@@ -851,7 +855,7 @@ __device__ __forceinline__ void flat_edges(const KParams& p, unsigned char* wscr
     const int lane = threadIdx.x & 63;
     constexpr u32 kWaves = BLOCK / 64;
     constexpr int W = kFlatW;
-    const u32 wave = (u32)threadIdx.x >> 6;
+    const u32 wave = wave_id();
     const u32 per = min(64u, (n_entries + kWaves - 1) / kWaves);         // entries per wave and round
     for (u32 base = wave * per; base < n_entries; base += kWaves * per) {
         const u32 cnt = min(per, n_entries - base);
@@ -913,7 +917,7 @@ __device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lk
                                              u32 n_short, u32 n_long, u32 part, u32 parts, bool dry = false)
 {
     u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
-    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * (threadIdx.x >> 6);
+    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave_id();
     // hub chunks (<= kSplitLen columns each) grow from the back of the push buffer, the other ranges from its front
     if (n_long)  expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, part, parts, dry);
     if (n_short) expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push, 1, n_short, part, parts, dry);
@@ -1028,7 +1032,7 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
                                          long long row, int seed, u32 seg_begin, u32 seg_len, int n_levels,
                                          int /*unused*/ GP_SUB_PARAMS)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)wave_id();
     u32*  hist = (u32*)scratch;                                      // [kTopkBins]
     Cand* sel  = (Cand*)(scratch + kTopkBins * sizeof(u32));         // [K]
     Cand* tie  = sel + p.K;                                          // [kBucketCap]
@@ -1578,7 +1582,7 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                 GP_SYNC();
                 GP_STAMP(t0);
                 {   // one lane per edge, like EXPAND
-                    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * (threadIdx.x >> 6);
+                    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave_id();
                     auto scatter = [&](const int (&v)[kFlatW], const double (&sh)[kFlatW]) {
 #pragma unroll
                         for (int w = 0; w < kFlatW; ++w) {

@@ -54,6 +54,22 @@ namespace gp {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// Address spaces.  The row's phases (EXPAND, SCAN, TOP-K) are separate, NON-inlined functions so that each gets its own
+// register allocation (inlined into one 130 KB function they spilled 47 VGPRs and 180 SGPRs, and an edit in one loop moved
+// the allocation of all the others).  Across such a call boundary a plain pointer is generic and every LDS access would
+// become a flat_* instruction; so the phases take LDS *byte offsets* and rebuild address_space(3) pointers from them (the
+// address-space inference then keeps ds_* instructions), and they read the launch parameters straight from the kernel
+// argument segment with scalar loads (address_space(4)) instead of receiving a copy on the stack.
+#define GP_LDS  __attribute__((address_space(3)))
+#define GP_KARG __attribute__((address_space(4)))
+template <class T> __device__ __forceinline__ T* lds_at(u32 byte_off) { return (T*)(GP_LDS T*)(uintptr_t)byte_off; }
+__device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }     // states wave-uniformity of a value that arrived in a VGPR
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double uni(double x) {
+    const u64 b = (u64)__double_as_longlong(x);
+    return __longlong_as_double((long long)(((u64)uni((u32)(b >> 32)) << 32) | uni((u32)b)));
+}
+
 constexpr int    kEmpty      = -1;
 constexpr int    kSplitLen   = 128;     // a long CSR range is split into chunks of this many columns
 constexpr int    kLongLen    = 64;      // upper limit of KParams::long_len (ranges longer than long_len are expanded by a whole wave)
@@ -232,6 +248,15 @@ struct KParams {
     const u32* row_map; const u64* n_rows_dev; u32* retry_list; int queue_counter;
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
+// The launch parameters where the hardware put them: the kernel argument segment (KParams is the kernels' only argument),
+// read with scalar loads.  __builtin_amdgcn_kernarg_segment_ptr() is only meaningful inside the kernel function itself
+// (a called function gets a null pointer), but the implicit-argument pointer IS part of the calling convention, and the
+// hidden arguments start right behind the explicit ones (8-byte aligned): the segment begins sizeof(KParams) before it.
+typedef const GP_KARG KParams& KP;
+static_assert(sizeof(KParams) % 8 == 0, "kparams(): the hidden kernel arguments must start right behind KParams");
+__device__ __forceinline__ KP kparams() {
+    return *(const GP_KARG KParams*)((const GP_KARG char*)__builtin_amdgcn_implicitarg_ptr() - sizeof(KParams));
+}
 
 // ---------------------------------------------------------------- small helpers
 // Multiplicative (Fibonacci-style) hashes; slot_of() consumes the HIGH bits.
@@ -503,7 +528,7 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
 // Since scan_level_dense took over the LDS tables this form is only instantiated for the HBM
 // table (IN_LDS = false): levels beyond kMaxParts partitions and the force_global test option.
 template <int BLOCK, bool IN_LDS, int U>
-__device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
+__device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                            ResRec* resg, u32 cap, int* log_key, double* log_val,
                                            PushEntry* push, double c, bool do_push)
 {
@@ -641,7 +666,7 @@ __device__ __forceinline__ void scan_level(const KParams& p, Ctl* ctl, LevelCtr*
 // order -- and (c) the nodes are then processed 64 at a time with every lane busy.
 // Requires C % 4 == 0 and the invariant that slots in [cap, C) are empty.
 template <int BLOCK>
-__device__ __forceinline__ void scan_level_dense(const KParams& p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
+__device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                                  u32 cap, u32 C, int* log_key, double* log_val,
                                                  PushEntry* push, double c, bool do_push)
 {
@@ -849,7 +874,7 @@ __device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* r
 // The edge enumeration of expand_flat, shared with the SCATTER of bucketed levels: calls f(v, share) with kFlatW
 // 64-edge windows per step (v[w] < 0 marks a lane past the end of the batch).
 template <int BLOCK, class F>
-__device__ __forceinline__ void flat_edges(const KParams& p, unsigned char* wscr, const PushEntry* list, long long stride_sign,
+__device__ __forceinline__ void flat_edges(KP p, unsigned char* wscr, const PushEntry* list, long long stride_sign,
                                            u32 n_entries, bool dry, F f)
 {
     const int lane = threadIdx.x & 63;
@@ -891,7 +916,7 @@ __device__ __forceinline__ void flat_edges(const KParams& p, unsigned char* wscr
 }
 
 template <int BLOCK, bool IN_LDS, bool DIRECT>
-__device__ __forceinline__ void expand_flat(const KParams& p, u32* flag, unsigned char* wscr, int* lkeys, double* lvals, ResRec* resg, u32 cap,
+__device__ __forceinline__ void expand_flat(KP p, u32* flag, unsigned char* wscr, int* lkeys, double* lvals, ResRec* resg, u32 cap,
                                             const PushEntry* list, long long stride_sign, u32 n_entries,
                                             u32 part, u32 parts, bool dry = false)
 {
@@ -912,7 +937,7 @@ __device__ __forceinline__ void expand_flat(const KParams& p, u32* flag, unsigne
 }
 
 template <int BLOCK, bool IN_LDS, bool DIRECT = false>
-__device__ __forceinline__ void expand_level(const KParams& p, Ctl* ctl, int* lkeys, double* lvals,
+__device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double* lvals,
                                              ResRec* resg, u32 cap, const PushEntry* push,
                                              u32 n_short, u32 n_long, u32 part, u32 parts, bool dry = false)
 {
@@ -1027,7 +1052,7 @@ __device__ __forceinline__ void load_log_records(const int* log_key, const doubl
 // 2. MSD radix select with 12-bit digits; as soon as the bucket holding the K-th value fits
 //    `big`, it is compacted into LDS and the remaining passes never touch HBM again.
 template <int BLOCK>
-__device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned char* scratch, u32 scratch_bytes,
+__device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch, u32 scratch_bytes,
                                          const int* log_key, const double* log_val, Cand* cand,
                                          long long row, int seed, u32 seg_begin, u32 seg_len, int n_levels,
                                          int /*unused*/ GP_SUB_PARAMS)
@@ -1381,24 +1406,228 @@ __device__ __forceinline__ void topk_row(const KParams& p, Ctl* ctl, unsigned ch
 #ifndef GP_MINW_1024
 #define GP_MINW_1024 4         // 8: two 1024-thread workgroups per CU with 64 VGPRs (tools/ab.sh experiments)
 #endif
+// ---------------------------------------------------------------- phases as separate functions
+// What a phase needs to find its workgroup's state again: everything hangs off the kernel arguments, the workgroup index
+// and the start of dynamic LDS.
+struct WgView {
+    Ctl* ctl; double* lvals; int* lkeys; u32 C;
+    PushEntry* push2; ResRec* resg; int* log_key; double* log_val; Cand* cand; ResRec* bucket;
+};
+__device__ __forceinline__ WgView wg_view(KP p, u32 lds0) {
+    WgView w;
+    w.C = p.lds_slots;
+    w.ctl = lds_at<Ctl>(lds0);
+    w.lvals = lds_at<double>(lds0 + (u32)kCtlBytes);
+    w.lkeys = lds_at<int>(lds0 + (u32)kCtlBytes + 8u * w.C);
+    const size_t wg = blockIdx.x;
+    w.push2   = p.push + wg * 2 * p.push_cap;
+    w.resg    = p.resg + wg * p.resg_cap;
+    w.log_key = p.log_key + wg * p.log_cap;
+    w.log_val = p.log_val + wg * p.log_cap;
+    w.cand    = p.cand + wg * p.cand_cap;
+    w.bucket  = p.bucket + wg * p.bucket_cap;
+    return w;
+}
+#ifdef GP_DIAG
+#define GP_PHASE_NOINLINE __attribute__((noinline))
+#else
+#define GP_PHASE_NOINLINE __attribute__((noinline))
+#endif
+
+// EXPAND of one level (or one hash partition of it).  MODE 0: LDS hash table, 1: HBM table, 2: direct-indexed LDS table.
+template <int BLOCK, int MODE>
+__device__ GP_PHASE_NOINLINE void phase_expand(u32 lds0, u32 cap, u32 cur, u32 n_short, u32 n_long, u32 part, u32 np,
+                                               u32 has_dang, double dang, int seed_key, u32 dry)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); cap = uni(cap); cur = uni(cur); n_short = uni(n_short); n_long = uni(n_long); part = uni(part); np = uni(np);
+    has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); dry = uni(dry);
+    const WgView w = wg_view(p, lds0);
+    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
+    expand_level<BLOCK, MODE != 1, MODE == 2>(p, w.ctl, w.lkeys, w.lvals, w.resg, cap, push_cur, n_short, n_long, part, np, dry != 0);
+    if (threadIdx.x == 0 && has_dang && !dry) {                                                    // graph.h:92
+        if (MODE == 2) res_add_direct(w.lkeys, w.lvals, p.node_mask, seed_key, dang);
+        else if (np == 1 || slot_of(hash_b((u32)seed_key), np) == part) {
+            const bool ok = MODE == 0 ? res_add_lds(w.lkeys, w.lvals, cap, seed_key, dang)
+                                      : res_add_hbm(w.resg, cap, seed_key, dang);
+            if (!ok) { if (MODE == 0) w.ctl->ovf = 1; else w.ctl->fail = 1; }
+        }
+    }
+}
+
+// SCAN of one level's (or partition's) LDS table; what it produces for the next level goes to ctl->lc[nx_sel] and to the
+// push buffer nxt_sel.
 template <int BLOCK>
-__device__ __forceinline__ void gfpush_rows(const KParams& p)
+__device__ GP_PHASE_NOINLINE void phase_scan_dense(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, double c, u32 do_push)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); c = uni(c); do_push = uni(do_push);
+    const WgView w = wg_view(p, lds0);
+    scan_level_dense<BLOCK>(p, w.ctl, &w.ctl->lc[nx_sel], w.lkeys, w.lvals, cap, w.C, w.log_key, w.log_val,
+                            w.push2 + (size_t)nxt_sel * p.push_cap, c, do_push != 0);
+}
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_scan_hbm(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, double c, u32 do_push)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); c = uni(c); do_push = uni(do_push);
+    const WgView w = wg_view(p, lds0);
+    scan_level<BLOCK, false, 4>(p, w.ctl, &w.ctl->lc[nx_sel], w.lkeys, w.lvals, w.resg, cap, w.log_key, w.log_val,
+                                w.push2 + (size_t)nxt_sel * p.push_cap, c, do_push != 0);
+}
+
+// The empty LDS table (start of the kernel, after TOP-K used the region as scratch, after an overflowing partition).
+template <int BLOCK>
+__device__ __forceinline__ void wipe_table(int* lkeys, double* lvals, u32 C) {
+    for (u32 i = threadIdx.x; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+}
+
+#ifdef GP_DIAG
+#define GP_TK_PARAMS , u64* tkd
+#define GP_TK_ARGS , tkd
+#define GP_TK_ACC(i, a, b) do { if (threadIdx.x == 0) tkd[i] += (b) - (a); } while (0)
+#else
+#define GP_TK_PARAMS
+#define GP_TK_ARGS
+#define GP_TK_ACC(i, a, b) do { } while (0)
+#endif
+
+// A level that needs several LDS partitions, with its edges bucketed in HBM once: SCATTER of (key, share) records into
+// fixed-stride per-bucket runs (one lane per edge, like EXPAND), then one insert pass + SCAN per bucket.  Returns 0 when a
+// bucket run overflowed (a hub collected the level's edges): the caller then takes the hash-partition walk.
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, u32 cur, u32 n_short, u32 n_long,
+                                                      u32 has_dang, double dang, int seed_key, u32 nx_sel, double c, u32 do_push GP_TK_PARAMS)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); cap = uni(cap); P = uni(P); cur = uni(cur); n_short = uni(n_short); n_long = uni(n_long);
+    has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); nx_sel = uni(nx_sel); c = uni(c); do_push = uni(do_push);
+    const WgView w = wg_view(p, lds0);
+    Ctl* ctl = w.ctl;
+    int* lkeys = w.lkeys; double* lvals = w.lvals;
+    const int tid = threadIdx.x;
+    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
+    ResRec* bucket = w.bucket;
+    u64 t0 = 0, t1 = 0, t2 = 0; (void)t0; (void)t1; (void)t2;
+    // SCATTER into fixed-stride buckets: hash buckets of one level are nearly equal, and the
+    // buffer is sized for the worst level the bounds allow (E_max), typically ~10x this one, so
+    // a run of bucket_cap / P records per bucket almost never overflows and the edges are visited
+    // twice (scatter, insert) instead of three times (count, scatter, insert).
+    const u32 stride = (u32)min((u64)0xFFFFFFFFu, p.bucket_cap / P);
+    if (tid < 64) ctl->bcnt[tid] = 0;
+    if (tid == 0) ctl->bovf = 0;
+    GP_SYNC();
+    GP_STAMP(t0);
+    {   // one lane per edge, like EXPAND
+        unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave_id();
+        auto scatter = [&](const int (&v)[kFlatW], const double (&sh)[kFlatW]) {
+#pragma unroll
+            for (int q = 0; q < kFlatW; ++q) {
+                if (v[q] < 0) continue;
+                const u32 bk = slot_of(hash_b((u32)v[q]), P);
+                const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (i < stride) { ResRec r; r.key = v[q]; r.pad = 0; r.val = sh[q]; bucket[(u64)bk * stride + i] = r; }
+                else ctl->bovf = 1;
+            }
+        };
+        if (n_long)  flat_edges<BLOCK>(p, wscr, push_cur + (p.push_cap - 1), -1, n_long, false, scatter);
+        if (n_short) flat_edges<BLOCK>(p, wscr, push_cur, 1, n_short, false, scatter);
+    }
+    GP_SYNC();
+    GP_STAMP(t1); GP_TK_ACC(0, t0, t1);
+    if (ctl->bovf) return 0u;
+    if (tid < 64 && (u32)tid < P) ctl->boff[tid] = (u32)tid * stride;
+    GP_SYNC();
+    // one insert pass per bucket, refined in place (q of Q sub-partitions) if it still overflows
+    for (u32 b = 0; b < P && !ctl->fail; ++b) {
+        const u32 lo = ctl->boff[b], hi = lo + ctl->bcnt[b];
+        u32 q = 0, Q = 1;
+        for (;;) {
+            GP_STAMP(t0);
+            GP_TK_ACC(2, 0, 1);
+            const u32 want = b * Q + q, fine = P * Q;
+            bool ok = true;
+            for (u32 base = lo; base < hi; base += 4 * BLOCK) {
+                ResRec rr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const u32 i = base + (u32)u * BLOCK + tid;
+                    rr[u].key = kEmpty; rr[u].val = 0.0;
+                    if (i < hi) rr[u] = bucket[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (rr[u].key != kEmpty && (Q == 1 || slot_of(hash_b((u32)rr[u].key), fine) == want))
+                        ok &= res_add_lds(lkeys, lvals, cap, rr[u].key, rr[u].val);          // graph.h:98
+            }
+            if (tid == 0 && has_dang && slot_of(hash_b((u32)seed_key), fine) == want)       // graph.h:92
+                ok &= res_add_lds(lkeys, lvals, cap, seed_key, dang);
+            if (!ok) ctl->ovf = 1;
+            GP_SYNC();
+            GP_STAMP(t1); GP_TK_ACC(0, t0, t1);
+            if (ctl->ovf) {
+                wipe_table<BLOCK>(lkeys, lvals, w.C);
+                GP_SYNC();
+                if (tid == 0) ctl->ovf = 0;
+                if (Q < (1u << 20)) { q *= 2; Q *= 2; GP_SYNC(); continue; }
+                if (tid == 0) ctl->fail = 1;
+                GP_SYNC();
+                break;
+            }
+            phase_scan_dense<BLOCK>(lds0, cap, nx_sel, cur ^ 1u, c, do_push);
+            GP_SYNC();
+            GP_STAMP(t2); GP_TK_ACC(1, t1, t2);
+            if (ctl->fail) break;
+            while (Q > 1 && (q & 1u)) { q >>= 1; Q >>= 1; }
+            ++q;
+            if (Q == 1) break;
+        }
+    }
+    return 1u;
+}
+
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_topk(u32 lds0, u32 row_lo, u32 row_hi, int seed, u32 seg_begin, u32 seg_len, int n_levels GP_SUB_PARAMS)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); row_lo = uni(row_lo); row_hi = uni(row_hi); seed = uni(seed); seg_begin = uni(seg_begin); seg_len = uni(seg_len);
+    n_levels = uni(n_levels);
+    const WgView w = wg_view(p, lds0);
+    topk_row<BLOCK>(p, w.ctl, (unsigned char*)w.lvals, 12u * w.C, w.log_key, w.log_val, w.cand,
+                    (long long)(((u64)row_hi << 32) | row_lo), seed, seg_begin, seg_len, n_levels, 0 GP_SUB_ARGS);
+}
+
+// ---------------------------------------------------------------- the kernel
+// Register budget: 1024 threads = 4 waves/SIMD = 128 VGPRs.  The 512- and 256-thread forms are
+// built for the SAME 4 waves/SIMD so that 2 (resp. 4) workgroups can share a CU and overlap
+// one row's barriers and memory stalls with another row's work.
+#ifndef GP_MINW_512
+#define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
+#endif
+#ifndef GP_MINW_768
+#define GP_MINW_768 3
+#endif
+#ifndef GP_MINW_1024
+#define GP_MINW_1024 4         // 8: two 1024-thread workgroups per CU with 64 VGPRs (tools/ab.sh experiments)
+#endif
+template <int BLOCK>
+__device__ __forceinline__ void gfpush_rows()
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Ctl* ctl   = (Ctl*)smem;
-    double* lvals = (double*)(smem + kCtlBytes);
-    int* lkeys = (int*)(smem + kCtlBytes + 8 * (size_t)p.lds_slots);
+    KP p = kparams();
+    const u32 lds0 = uni(lds_addr(smem));
+    const WgView w = wg_view(p, lds0);
+    Ctl* ctl = w.ctl;
+    double* lvals = w.lvals;
+    int* lkeys = w.lkeys;
     const int tid = threadIdx.x;
-    const u32 C = p.lds_slots;
+    const u32 C = w.C;
+    PushEntry* push2 = w.push2;
+    ResRec* resg     = w.resg;
+    int* log_key     = w.log_key;
+    double* log_val  = w.log_val;
 
-    const size_t wg = blockIdx.x;
-    PushEntry* push2 = p.push + wg * 2 * p.push_cap;
-    ResRec* resg     = p.resg + wg * p.resg_cap;
-    int* log_key     = p.log_key + wg * p.log_cap;
-    double* log_val  = p.log_val + wg * p.log_cap;
-    Cand* cand       = p.cand + wg * p.cand_cap;
-
-    for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+    wipe_table<BLOCK>(lkeys, lvals, C);
     if (tid < (int)(sizeof(ctl->st) / sizeof(ctl->st[0]))) { ctl->st[tid] = 0; ctl->st_row[tid] = 0; }      // visible after the first row's barriers
     const long long n_rows = p.n_rows_dev ? (long long)*p.n_rows_dev : p.n_seeds;    // rows in this launch's queue
     u32 max_e = 0, max_log = 0;                                                      // observed maxima of this workgroup
@@ -1513,6 +1742,7 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
             cur = 1;
             GP_SYNC();                            // push entries / fail flag visible to every wave
         }
+        (void)e_short_cur;
 #ifdef GP_DIAG
         GP_STAMP(rs2);
         const u64 lv_all_e0 = tk_expand, lv_all_s0 = tk_scan;
@@ -1542,8 +1772,6 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                     if (parts > kMaxParts) in_lds = false;
                 }
             }
-            PushEntry* push_cur = push2 + (size_t)cur * p.push_cap;
-            PushEntry* push_nxt = push2 + (size_t)(cur ^ 1) * p.push_cap;
             const u32 snap_log = ctl->log_count;          // first log record of this level
 #ifdef GP_DIAG
             const u64 lv_e0 = tk_expand, lv_s0 = tk_scan; u32 lv_passes = 0;
@@ -1568,88 +1796,17 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
             const bool bucketed = in_lds && parts >= kBucketMin && parts <= 64 &&
                                   (u64)e_cur + 1 <= p.bucket_cap;
             bool use_buckets = !ctl->fail && bucketed;
-            ResRec* bucket = p.bucket + wg * p.bucket_cap;
-            const u32 P = parts;
             if (use_buckets) {
-                // SCATTER into fixed-stride buckets: hash buckets of one level are nearly equal, and the
-                // buffer is sized for the worst level the bounds allow (E_max), typically ~10x this one, so
-                // a run of bucket_cap / P records per bucket almost never overflows and the edges are visited
-                // twice (scatter, insert) instead of three times (count, scatter, insert).  If a bucket does
-                // overflow (a hub collected a level's edges), the level takes the hash-partition walk below.
-                const u32 stride = (u32)min((u64)0xFFFFFFFFu, p.bucket_cap / P);
-                if (tid < 64) ctl->bcnt[tid] = 0;
-                if (tid == 0) ctl->bovf = 0;
-                GP_SYNC();
-                GP_STAMP(t0);
-                {   // one lane per edge, like EXPAND
-                    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave_id();
-                    auto scatter = [&](const int (&v)[kFlatW], const double (&sh)[kFlatW]) {
-#pragma unroll
-                        for (int w = 0; w < kFlatW; ++w) {
-                            if (v[w] < 0) continue;
-                            const u32 bk = slot_of(hash_b((u32)v[w]), P);
-                            const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (i < stride) { ResRec r; r.key = v[w]; r.pad = 0; r.val = sh[w]; bucket[(u64)bk * stride + i] = r; }
-                            else ctl->bovf = 1;
-                        }
-                    };
-                    if (n_long_cur) flat_edges<BLOCK>(p, wscr, push_cur + (p.push_cap - 1), -1, n_long_cur, false, scatter);
-                    if (n_push_cur) flat_edges<BLOCK>(p, wscr, push_cur, 1, n_push_cur, false, scatter);
-                }
-                GP_SYNC();
-                GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
-                if (ctl->bovf) use_buckets = false;
-                else { if (tid < 64 && (u32)tid < P) ctl->boff[tid] = (u32)tid * stride; GP_SYNC(); }
-            }
-            if (use_buckets) {
-                // one insert pass per bucket, refined in place (q of Q sub-partitions) if it still overflows
-                for (u32 b = 0; b < P && !ctl->fail; ++b) {
-                    const u32 lo = ctl->boff[b], hi = lo + ctl->bcnt[b];
-                    u32 q = 0, Q = 1;
-                    for (;;) {
-                        GP_STAMP(t0);
 #ifdef GP_DIAG
-                        ++lv_passes;
+                u64 tkd[3] = {0, 0, 0};
 #endif
-                        const u32 want = b * Q + q, fine = P * Q;
-                        bool ok = true;
-                        for (u32 base = lo; base < hi; base += 4 * BLOCK) {
-                            ResRec rr[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const u32 i = base + (u32)u * BLOCK + tid;
-                                rr[u].key = kEmpty; rr[u].val = 0.0;
-                                if (i < hi) rr[u] = bucket[i];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (rr[u].key != kEmpty && (Q == 1 || slot_of(hash_b((u32)rr[u].key), fine) == want))
-                                    ok &= res_add_lds(lkeys, lvals, cap, rr[u].key, rr[u].val);          // graph.h:98
-                        }
-                        if (tid == 0 && has_dang_cur && slot_of(hash_b((u32)seed_key), fine) == want)       // graph.h:92
-                            ok &= res_add_lds(lkeys, lvals, cap, seed_key, dang_cur);
-                        if (!ok) ctl->ovf = 1;
-                        GP_SYNC();
-                        GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1);
-                        if (ctl->ovf) {
-                            for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
-                            GP_SYNC();
-                            if (tid == 0) ctl->ovf = 0;
-                            if (Q < (1u << 20)) { q *= 2; Q *= 2; GP_SYNC(); continue; }
-                            if (tid == 0) ctl->fail = 1;
-                            GP_SYNC();
-                            break;
-                        }
-                        scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
-                        GP_SYNC();
-                        GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2);
-                        if (ctl->fail) break;
-                        while (Q > 1 && (q & 1u)) { q >>= 1; Q >>= 1; }
-                        ++q;
-                        if (Q == 1) break;
-                    }
-                }
-            } else if (!ctl->fail) {
+                use_buckets = phase_bucketed_level<BLOCK>(lds0, cap, parts, (u32)cur, n_push_cur, n_long_cur, has_dang_cur ? 1u : 0u, dang_cur,
+                                                          seed_key, (u32)(lvl & 1), c, do_push ? 1u : 0u GP_TK_ARGS) != 0;
+#ifdef GP_DIAG
+                tk_expand += tkd[0]; tk_scan += tkd[1]; lv_passes += (u32)tkd[2];
+#endif
+            }
+            if (!use_buckets && !ctl->fail) {
                 {
                     u32 part = 0, np = parts;
                     for (;;) {
@@ -1657,30 +1814,22 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
 #ifdef GP_DIAG
                         ++lv_passes;
 #endif
-                        {
-                            if (BLOCK == 512 && direct) {
-                                expand_level<BLOCK, true, BLOCK == 512>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np);
-                                if (tid == 0 && has_dang_cur) res_add_direct(lkeys, lvals, p.node_mask, seed_key, dang_cur);       // graph.h:92
-                            } else {
-                            if (in_lds) expand_level<BLOCK, true >(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np);
-                            else        expand_level<BLOCK, false>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np);
+                        if (BLOCK == 512 && direct) {
+                            phase_expand<BLOCK, BLOCK == 512 ? 2 : 0>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
+                        } else if (in_lds) {
+                            phase_expand<BLOCK, 0>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
 #ifdef GP_DIAG
-                            if ((p.diag_flags & 2) && in_lds) expand_level<BLOCK, true>(p, ctl, lkeys, lvals, resg, cap, push_cur, n_push_cur, n_long_cur, part, np, true);
+                            if (p.diag_flags & 2) phase_expand<BLOCK, 0>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, 0u, 0.0, seed_key, 1u);
 #endif
-                            if (tid == 0 && has_dang_cur &&
-                                (np == 1 || slot_of(hash_b((u32)seed_key), np) == part)) {          // graph.h:92
-                                const bool ok = in_lds ? res_add_lds(lkeys, lvals, cap, seed_key, dang_cur)
-                                                       : res_add_hbm(resg, cap, seed_key, dang_cur);
-                                if (!ok) { if (in_lds) ctl->ovf = 1; else ctl->fail = 1; }
-                            }
-                            }
+                        } else {
+                            phase_expand<BLOCK, 1>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
                         }
                         GP_SYNC();
                         GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1); if (!in_lds) GP_ACCUM(tk_expand_hbm, t0, t1);
                         if (ctl->fail) break;
                         if (ctl->ovf) {
                             // this partition did not fit: wipe the table and split it in two
-                            for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+                            wipe_table<BLOCK>(lkeys, lvals, C);
                             GP_SYNC();
                             if (tid == 0) ctl->ovf = 0;
                             if (np < 0x20000000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
@@ -1689,15 +1838,15 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
                             break;
                         }
                         if (in_lds) {
-                            scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
+                            phase_scan_dense<BLOCK>(lds0, cap, (u32)(lvl & 1), (u32)(cur ^ 1), c, do_push ? 1u : 0u);
 #ifdef GP_DIAG
                             if (p.diag_flags & 4) {                  // a second walk over the (now empty) table: cost of stage (a) alone
                                 GP_SYNC();
-                                scan_level_dense<BLOCK>(p, ctl, nx, lkeys, lvals, cap, C, log_key, log_val, push_nxt, c, do_push);
+                                phase_scan_dense<BLOCK>(lds0, cap, (u32)(lvl & 1), (u32)(cur ^ 1), c, do_push ? 1u : 0u);
                             }
 #endif
                         } else {
-                            scan_level<BLOCK, false, 4>(p, ctl, nx, lkeys, lvals, resg, cap, log_key, log_val, push_nxt, c, do_push);
+                            phase_scan_hbm<BLOCK>(lds0, cap, (u32)(lvl & 1), (u32)(cur ^ 1), c, do_push ? 1u : 0u);
                         }
                         GP_SYNC();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
@@ -1738,7 +1887,7 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
             if (failed) {
                 // Leave the row unwritten.  Restore clean tables so that later rows of this workgroup are unaffected.
                 give_up();
-                for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+                wipe_table<BLOCK>(lkeys, lvals, C);
                 for (u64 i = tid; i < p.resg_cap; i += BLOCK) { st_l2(&resg[i].key, kEmpty); st_l2(&resg[i].val, 0.0); }
                 continue;
             }
@@ -1752,13 +1901,13 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
         }
         if (!(p.diag_flags & 1))
 #endif
-        topk_row<BLOCK>(p, ctl, smem + kCtlBytes, 12u * C, log_key, log_val, cand, row, seed, seg_begin, seg_len, n_levels, 0 GP_SUB_ARGS);
+        phase_topk<BLOCK>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, seg_begin, seg_len, n_levels GP_SUB_ARGS);
         GP_SYNC();
         if (ctl->fail) give_up();                                      // the candidate array overflowed: nothing was written
         else if (tid < (int)sNumStats) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }      // the row is done: its counts count
         GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);
         // top-K used the table region as scratch: restore the empty LDS table
-        for (u32 i = tid; i < C; i += BLOCK) { lkeys[i] = kEmpty; lvals[i] = 0.0; }
+        wipe_table<BLOCK>(lkeys, lvals, C);
 #ifdef GP_DIAG
         GP_STAMP(rs3);
         if (tid == 0) __hip_atomic_fetch_add(&p.counters[kDiagX0 + 7], rs3 - t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1807,14 +1956,14 @@ __device__ __forceinline__ void gfpush_rows(const KParams& p)
 // The two launches of a call are separate kernel symbols so that profilers report them separately (the retry launch is a
 // few microseconds of nothing whenever no row outgrew its slab, and would halve the "average gfpush_kernel duration").
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? GP_MINW_768 : BLOCK == 512 ? GP_MINW_512 : BLOCK == 1024 ? GP_MINW_1024 : 4) gfpush_kernel(const KParams p)
+__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? GP_MINW_768 : BLOCK == 512 ? GP_MINW_512 : BLOCK == 1024 ? GP_MINW_1024 : 4) gfpush_kernel(const KParams)
 {
-    gfpush_rows<BLOCK>(p);
+    gfpush_rows<BLOCK>();
 }
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? GP_MINW_768 : BLOCK == 512 ? GP_MINW_512 : BLOCK == 1024 ? GP_MINW_1024 : 4) gfpush_retry_kernel(const KParams p)
+__global__ void __launch_bounds__(BLOCK, BLOCK == 768 ? GP_MINW_768 : BLOCK == 512 ? GP_MINW_512 : BLOCK == 1024 ? GP_MINW_1024 : 4) gfpush_retry_kernel(const KParams)
 {
-    gfpush_rows<BLOCK>(p);
+    gfpush_rows<BLOCK>();
 }
 
 // Fills the per-workgroup HBM residue tables with empty records (a byte memset cannot: val must be 0).

@@ -1401,7 +1401,7 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
 #define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
 #endif
 #ifndef GP_MINW_768
-#define GP_MINW_768 3
+#define GP_MINW_768 6          // two 768-thread workgroups per CU (6 waves per SIMD, 80 VGPRs)
 #endif
 #ifndef GP_MINW_1024
 #define GP_MINW_1024 4         // 8: two 1024-thread workgroups per CU with 64 VGPRs (tools/ab.sh experiments)
@@ -1605,7 +1605,7 @@ __device__ GP_PHASE_NOINLINE void phase_topk(u32 lds0, u32 row_lo, u32 row_hi, i
 #define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
 #endif
 #ifndef GP_MINW_768
-#define GP_MINW_768 3
+#define GP_MINW_768 6          // two 768-thread workgroups per CU (6 waves per SIMD, 80 VGPRs)
 #endif
 #ifndef GP_MINW_1024
 #define GP_MINW_1024 4         // 8: two 1024-thread workgroups per CU with 64 VGPRs (tools/ab.sh experiments)

@@ -342,6 +342,8 @@ const char* gp_last_error(void) { return g_last_error.c_str(); }
 
 int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indices, uint32_t* node_mask, void* stream) {
     if (!g) return fail(GP_ERR_NULL, "graph handle is NULL");
+    if (g->multi) g = g->part[0];                          // a multi-GPU handle owns no device memory itself: the CSR lives in part[0]
+    if (!g) return fail(GP_ERR_NULL, "graph handle has no device CSR");
     HIP_TRY(hipSetDevice(g->device));
     int rc = ensure_packed(g, (hipStream_t)stream);
     if (rc) return rc;
@@ -402,10 +404,11 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
     int rc = GP_OK;
     auto cleanup = [&](int status) { gp_graph_destroy(g); return status; };
     if (hipMalloc(&g->d_indptr, sizeof(int) * (size_t)(n_nodes + 1)) != hipSuccess ||
-        hipMalloc(&g->d_indices, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)) != hipSuccess)
+        hipMalloc(&g->d_indices, sizeof(int) * (size_t)(nnz + 1)) != hipSuccess)     // + the sentinel word indices[nnz] = -1
         return cleanup(fail(GP_ERR_NOMEM, "hipMalloc of the CSR (%lld nodes, %lld nnz) failed", (long long)n_nodes, (long long)nnz));
     if (hipMemcpy(g->d_indptr, indptr, sizeof(int) * (size_t)(n_nodes + 1), hipMemcpyHostToDevice) != hipSuccess ||
-        (nnz > 0 && hipMemcpy(g->d_indices, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess))
+        (nnz > 0 && hipMemcpy(g->d_indices, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemset(g->d_indices + nnz, 0xFF, sizeof(int)) != hipSuccess)        // lanes past the end of an edge batch load this word (EXPAND)
         return cleanup(fail(GP_ERR_HIP, "CSR upload failed"));
     if (hipMalloc(&g->d_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
         hipHostMalloc(&g->h_counters, sizeof(u64) * kNumCounters) != hipSuccess ||
@@ -598,7 +601,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     }
 
     KParams kp;
-    kp.indptr = g->d_indptr; kp.indices = g->d_indices; kp.n_nodes = (int)g->n_nodes;
+    kp.indptr = g->d_indptr; kp.indices = g->d_indices; kp.n_nodes = (int)g->n_nodes; kp.nnz = (int)g->nnz;
     kp.deg_shift = g->deg_shift; kp.node_mask = g->node_mask; kp.deg_sat = g->deg_sat;
     kp.seeds = d_seeds; kp.n_seeds = n_seeds;
     kp.coef = g->d_coef; kp.n_coef = n_coef; kp.rmax = rmax; kp.K = K;
@@ -826,14 +829,16 @@ int replicate_part(gp_graph* g, int d) {
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     gp_graph* q = new (std::nothrow) gp_graph();
     if (!q) return fail(GP_ERR_NOMEM, "host allocation failed");
-    g->part[d] = q;                                        // owned from here on (destroyed with the handle)
+    // Built completely before it is published in g->part[d]: a half-initialised part left behind by a failed allocation
+    // would be taken for a usable replica by every later call.
+    struct Guard { gp_graph* q; ~Guard() { if (q) gp_graph_destroy(q); } } guard{q};
     q->device = dev; q->n_nodes = src->n_nodes; q->nnz = src->nnz; q->num_cus = prop.multiProcessorCount;
     q->deg_shift = src->deg_shift; q->node_mask = src->node_mask; q->deg_sat = src->deg_sat;
     q->packed = true; q->max_degree_bits = src->max_degree_bits;
     q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
     q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
     q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges;
-    const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)std::max<int64_t>(q->nnz, 1);
+    const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));
     HIP_TRY(hipMemcpyPeer(q->d_indptr, dev, src->d_indptr, src->device, b_ptr));
@@ -843,6 +848,8 @@ int replicate_part(gp_graph* g, int d) {
     HIP_TRY(hipEventCreate(&q->ev0));
     HIP_TRY(hipEventCreate(&q->ev1));
     HIP_TRY(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+    guard.q = nullptr;
+    g->part[d] = q;                                        // owned by the handle from here on (destroyed with it)
     return GP_OK;
 }
 

@@ -65,6 +65,8 @@ typedef unsigned int u32;
 template <class T> __device__ __forceinline__ T* lds_at(u32 byte_off) { return (T*)(GP_LDS T*)(uintptr_t)byte_off; }
 __device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }     // states wave-uniformity of a value that arrived in a VGPR
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ u64 uni(u64 x) { return ((u64)uni((u32)(x >> 32)) << 32) | uni((u32)x); }
+__device__ __forceinline__ long long uni(long long x) { return (long long)uni((u64)x); }
 __device__ __forceinline__ double uni(double x) {
     const u64 b = (u64)__double_as_longlong(x);
     return __longlong_as_double((long long)(((u64)uni((u32)(b >> 32)) << 32) | uni((u32)b)));
@@ -75,6 +77,9 @@ constexpr int    kSplitLen   = 128;     // a long CSR range is split into chunks
 constexpr int    kLongLen    = 64;      // upper limit of KParams::long_len (ranges longer than long_len are expanded by a whole wave)
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
+#ifndef GP_EXPAND_STREAM
+#define GP_EXPAND_STREAM 1       // EXPAND into LDS hash tables: the pipelined per-wave stream (expand_stream); 0 = the flat_edges form
+#endif
 #ifndef GP_FLAT_W
 #define GP_FLAT_W 4
 #endif
@@ -145,6 +150,7 @@ struct Ctl {
 #ifdef GP_DIAG
     u64 barw[16];         // per wave: shader cycles spent waiting at workgroup barriers
     u32 barn[16];         // per wave: barriers passed
+    u64 exp_sub[8];       // wave 0: shader cycles in EXPAND (expand_stream): [0] prepare (edge -> entry, batch switches) [1] wait for the column loads [2] inserts [3] steps [4] batches [5] total [6] calls
     u64 scan_sub[4];      // wave 0: shader cycles in SCAN's (a,b) compaction / (c) records / (d) lookups + push entries / tail
     u64 site_w[64];       // per GP_SYNC() site (in source order): shader cycles all waves waited there
     u32 site_n[64];       // per site: wave arrivals
@@ -224,6 +230,7 @@ constexpr int kSyncBase = __COUNTER__;
 
 struct KParams {
     const int* indptr; const int* indices; int n_nodes;
+    int nnz;                              // indices[nnz] is a sentinel word (-1): what lanes past the end of an edge batch load
     // Device `indices` words are PACKED: column id in the low `deg_shift` bits, min(deg(column), deg_sat)
     // above them (sign bit clear).  The degree of every push target thus arrives with its id.
     int deg_shift; u32 node_mask; u32 deg_sat;
@@ -936,6 +943,9 @@ __device__ __forceinline__ void expand_flat(KP p, u32* flag, unsigned char* wscr
     });
 }
 
+template <int BLOCK>
+__device__ __forceinline__ void expand_stream(KP p, Ctl* ctl, int* lkeys, double* lvals, u32 cap, const PushEntry* push,
+                                              u32 n_short, u32 n_long, u32 part, u32 parts, bool dry);
 template <int BLOCK, bool IN_LDS, bool DIRECT = false>
 __device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double* lvals,
                                              ResRec* resg, u32 cap, const PushEntry* push,
@@ -944,8 +954,138 @@ __device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double*
     u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave_id();
     // hub chunks (<= kSplitLen columns each) grow from the back of the push buffer, the other ranges from its front
+#if GP_EXPAND_STREAM
+    if (IN_LDS && !DIRECT) { expand_stream<BLOCK>(p, ctl, lkeys, lvals, cap, push, n_short, n_long, part, parts, dry); return; }
+#endif
     if (n_long)  expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, part, parts, dry);
     if (n_short) expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push, 1, n_short, part, parts, dry);
+}
+
+// ---------------------------------------------------------------- EXPAND into an LDS hash table: one pipelined stream per wave
+// Same edge enumeration as flat_edges (one lane per edge, windows of 64, four windows per step), restructured around what
+// the wave WAITS for.  A step of the old form was a chain of ~8 LDS round trips (flag byte, then three ds_bpermute, per
+// window), one HBM round trip for the column ids, and four serial probing chains -- roughly a third each of its ~5.5 k
+// cycles, with 32 of 80 VGPRs in use.  Here
+//   * the flags of a step's four windows lie transposed (byte w of word `lane`), so ONE ds_read_b32 fetches all four and
+//     the twelve ds_bpermute of the step issue back to back: two LDS round trips instead of eight;
+//   * the long (hub-chunk) and short entries of the wave form ONE stream of steps, and the column loads of step s+1 are
+//     issued BEFORE the inserts of step s (12 more live registers): the HBM latency of all but the first step of a stream
+//     is hidden behind the previous step's probing chains.
+template <int BLOCK>
+__device__ __forceinline__ void expand_stream(KP p, Ctl* ctl, int* lkeys, double* lvals, u32 cap, const PushEntry* push,
+                                              u32 n_short, u32 n_long, u32 part, u32 parts, bool dry)
+{
+    constexpr u32 kWaves = BLOCK / 64;
+    static_assert(kFlatW == 4, "expand_stream reads the four window flags of a lane as one 32-bit word");
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = wave_id();
+    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave;
+    u32* flag = &ctl->ovf;
+    const int* indices = p.indices;
+    const u32 per_l = min(64u, (n_long + kWaves - 1) / kWaves), per_s = min(64u, (n_short + kWaves - 1) / kWaves);
+    const PushEntry* long0 = push + (p.push_cap - 1);
+    // the wave's position in its stream: list (0 = long chunks, from the back of the buffer; 1 = short ranges), next batch, next step
+    u32 which = 0, base = wave * per_l;
+    int rel = 0; u32 len = 0, excl = 0, T = 0, t = 0; double share = 0.0;
+
+#ifdef GP_DIAG
+    u64 xs[7] = {0, 0, 0, 0, 0, 0, 1}; u64 x0 = clock64(), xa = x0, xb;
+#define GP_XS(i) do { xb = clock64(); xs[i] += xb - xa; xa = xb; } while (0)
+#define GP_XS_FLUSH() do { xs[5] = clock64() - x0; if (threadIdx.x == 0) for (int i_ = 0; i_ < 7; ++i_) ctl->exp_sub[i_] += xs[i_]; } while (0)
+#else
+#define GP_XS(i) do { } while (0)
+#define GP_XS_FLUSH() do { } while (0)
+#endif
+    // Prepares the next step of the stream: the element index of every lane's column word (lanes past the end of the batch,
+    // and every lane once the stream has ended, get the sentinel word indices[nnz] = -1) and the share of its entry.
+    // Returns false once the stream has ended.
+    auto prepare = [&](u32 (&idx)[4], double (&sh)[4]) -> bool {
+        bool live = true;
+        while (t >= T) {                                                       // next batch of <= 64 entries (wave-uniform)
+            if (which == 0 && base >= n_long) { which = 1; base = wave * per_s; }
+            if (which == 1 && base >= n_short) { live = false; break; }
+            const u32 n = which == 0 ? n_long : n_short, per = which == 0 ? per_l : per_s;
+            const u32 cnt = min(per, n - base);
+            int start = 0; len = 0; share = 0.0;
+            if (lane < cnt) {
+                const PushEntry pe = which == 0 ? long0[-(long long)(base + lane)] : push[base + lane];
+                start = pe.start; len = (u32)pe.len; share = dry ? 0.0 : pe.share;
+            }
+            base += kWaves * per;
+            const u32 incl = wave_incl_scan_dpp(len);
+            excl = incl - len;                                                 // first edge of my entry inside the batch
+            T = (u32)__builtin_amdgcn_readlane((int)incl, 63);                 // edges of the batch
+            rel = start - (int)excl;                                           // column index of edge q = rel(owner) + q   graph.h:97
+            t = 0;
+#ifdef GP_DIAG
+            xs[4] += 1;
+#endif
+        }
+        if (!live) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { idx[w] = (u32)p.nnz; sh[w] = 0.0; }
+            return false;
+        }
+        // edge -> entry: entries that start inside the step flag their first edge (LDS operations of one wave execute in order)
+        *(u32*)(wscr + 4 * lane) = 0u;
+        if (len != 0 && excl > t && excl < t + 256u) { const u32 pos = excl - t; wscr[(pos & 63u) * 4u + (pos >> 6)] = 1; }
+        asm volatile("" ::: "memory");        // the word is written by OTHER lanes: without this the compiler forwards this lane's own 0
+        const u32 f = *(const u32*)(wscr + 4 * lane);
+        u32 before = (u32)__popcll(__ballot(len != 0 && excl <= t)) - 1u;      // owner of edge t (wave-uniform)
+        u32 e[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const bool mine = ((f >> (8 * w)) & 1u) != 0;
+            const u64 M = __ballot(mine);
+            e[w] = (before + lane_prefix(M) + (mine ? 1u : 0u)) << 2;          // byte address of the owning lane for ds_bpermute
+            before += (u32)__popcll(M);
+        }
+        const u64 sbits = (u64)__double_as_longlong(share);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int rel_e = __builtin_amdgcn_ds_bpermute((int)e[w], rel);
+            const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)e[w], (int)(u32)sbits);
+            const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)e[w], (int)(u32)(sbits >> 32));
+            const u32 q = t + 64u * (u32)w + lane;
+            idx[w] = q < T ? (u32)(rel_e + (int)q) : (u32)p.nnz;
+            sh[w] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+        }
+        t += 256u;
+        return true;
+    };
+    // One loop, one basic block per iteration behind the batch switch: prepare step s+1 (LDS only), take over the columns
+    // of step s (their loads have been in flight since the previous iteration), issue the loads of step s+1, insert step s.
+    // The loads are unconditional (a finished stream loads the sentinel word once more), so nothing between "issue" and
+    // "consume" merges control flow and the compiler's wait counts stay exact.
+    int nc[4]; double ns[4];
+    {
+        u32 idx[4];
+        if (!prepare(idx, ns)) { GP_XS_FLUSH(); return; }
+        GP_XS(0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) nc[w] = indices[idx[w]];                   // graph.h:97
+    }
+    bool live = true;
+    while (live) {
+        u32 idx[4]; double sh[4];
+        live = prepare(idx, sh);
+        GP_XS(0);
+        int cc[4]; double cs[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; cs[w] = ns[w]; }
+#ifdef GP_DIAG
+        if (cc[0] == 0x7FFFFFF0 && cc[1] == 0x7FFFFFF0 && cc[2] == 0x7FFFFFF0 && cc[3] == 0x7FFFFFF0) xs[6] += 1;      // (uses the loaded values: the wait is charged here)
+        GP_XS(1); xs[3] += 1;
+#endif
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; ns[w] = sh[w]; }
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (cc[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)cc[w]), parts) == part))
+                res_add_lds_flag(lkeys, lvals, cap, cc[w], cs[w], flag);      // graph.h:98
+        GP_XS(2);
+    }
+    GP_XS_FLUSH();
 }
 
 // ---------------------------------------------------------------- bucketed levels
@@ -1640,6 +1780,7 @@ __device__ __forceinline__ void gfpush_rows()
     for (int i = 0; i < 16; ++i) gp_sub_acc[i] = 0;
     if (tid < 16) { ctl->barw[tid] = 0; ctl->barn[tid] = 0; }
     if (tid < 4) ctl->scan_sub[tid] = 0;
+    if (tid < 8) ctl->exp_sub[tid] = 0;
     if (tid < 64) { ctl->site_w[tid] = 0; ctl->site_n[tid] = 0; }
     const u64 wave_t0 = clock64();
 #endif
@@ -1659,10 +1800,10 @@ __device__ __forceinline__ void gfpush_rows()
             ctl->n_sel = 0; ctl->n_bucket = 0;
         }
         GP_SYNC();
-        const long long qpos = ctl->row;
+        const long long qpos = uni(ctl->row);
         if (qpos >= n_rows) break;
-        const long long row = p.row_map ? (long long)p.row_map[qpos] : qpos;
-        const int seed = p.seeds[row];
+        const long long row = p.row_map ? (long long)uni(p.row_map[qpos]) : qpos;
+        const int seed = uni(p.seeds[row]);
         if (seed < 0 || seed >= p.n_nodes) {            // device API does not pre-validate seeds
             if (tid == 0) { stat_add_final(ctl, sFailed, 1); if (p.out_filled) p.out_filled[row] = 0; }
             continue;
@@ -1683,13 +1824,14 @@ __device__ __forceinline__ void gfpush_rows()
         };
 
         // the seed's table key carries its degree like every packed column id
-        const u32 seed_deg = (u32)(p.indptr[seed + 1] - p.indptr[seed]);
+        const u32 s_start = uni((u32)p.indptr[seed]);
+        const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - s_start;
         const int seed_key = (int)((u32)seed | (min(seed_deg, p.deg_sat) << p.deg_shift));
 #ifdef GP_DIAG
         if (tid == 0 && seed_deg != 0xFFFFFFFFu) rs1 = wall_clock64();     // after the queue -> seed -> indptr chain
 #endif
         // state of the level about to be produced: its push list (built by the previous SCAN)
-        u32 n_push_cur = 0, n_long_cur = 0, e_cur = 0, e_short_cur = 0;
+        u32 n_push_cur = 0, n_long_cur = 0, e_cur = 0;
         u32 seg_begin = 0, seg_len = 0; int n_levels = 0;     // biggest level of the reserve log (coef > 0)
         double dang_cur = 0.0;
         bool has_dang_cur = false;
@@ -1699,8 +1841,7 @@ __device__ __forceinline__ void gfpush_rows()
         //      record, its push test and its push-list entries are written directly.  This removes one
         //      EXPAND/SCAN round trip (two barriers, a table walk and a dependent indptr load) per row.
         {
-            const double c0 = p.coef[0];
-            const u32 s_start = (u32)p.indptr[seed];
+            const double c0 = uni(p.coef[0]);
             PushEntry* push_nxt0 = push2 + (size_t)1 * p.push_cap;
             if (tid == 0) {
                 if (p.log_cap > 0) { log_key[0] = seed_key; log_val[0] = c0; }                         // graph.h:90 / :109
@@ -1719,7 +1860,7 @@ __device__ __forceinline__ void gfpush_rows()
                     if (share != 0.0) {
                         e_cur = seed_deg;
                         if (seed_deg <= p.long_len) {
-                            n_push_cur = 1; e_short_cur = seed_deg;
+                            n_push_cur = 1;
                             if (tid == 0) {
                                 if (p.push_cap > 0) { PushEntry pe; pe.start = (int)s_start; pe.len = (int)seed_deg; pe.share = share; push_nxt0[0] = pe; }
                                 else ctl->fail = 1;
@@ -1742,13 +1883,12 @@ __device__ __forceinline__ void gfpush_rows()
             cur = 1;
             GP_SYNC();                            // push entries / fail flag visible to every wave
         }
-        (void)e_short_cur;
 #ifdef GP_DIAG
         GP_STAMP(rs2);
         const u64 lv_all_e0 = tk_expand, lv_all_s0 = tk_scan;
 #endif
         for (int lvl = 1; lvl <= L; ++lvl) {
-            const double c = p.coef[lvl];
+            const double c = uni(p.coef[lvl]);
             const bool do_push = lvl < L;                                     // graph.h:83 vs :104
             // distinct targets of this level <= min(edges (+ the seed), N)
             const u64 need = min((u64)e_cur + (has_dang_cur ? 1 : 0), (u64)p.n_nodes);
@@ -1763,16 +1903,18 @@ __device__ __forceinline__ void gfpush_rows()
                 cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
             } else if (in_lds) {
                 if (need * 4 <= (u64)C * 3) {
-                    cap = (u32)min((u64)C, max((u64)kMinCap, (((u64)GP_CAP_MULT * need) + 3) & ~3ull));
+                    cap = min(C, max(kMinCap, ((u32)GP_CAP_MULT * (u32)need + 3u) & ~3u));
+                } else if (need > (u64)kMaxParts * C) {
+                    in_lds = false;                      // more than kMaxParts partitions: the HBM table
                 } else {
                     // target load of a partition: 0.75 of the table counted in EDGES (distinct targets are ~15 % fewer); a partition
                     // that overflows anyway is split in place.  0.55 -> 0.75 saved half a pass on the peak levels of the 80 KB shape (+2 %).
-                    parts = (u32)((need * 20 + (u64)C * 15 - 1) / ((u64)C * 15));
+                    parts = ((u32)need * 4u + C * 3u - 1u) / (C * 3u);       // need <= 64 C < 2^21: 32-bit arithmetic
                     cap = C;
                     if (parts > kMaxParts) in_lds = false;
                 }
             }
-            const u32 snap_log = ctl->log_count;          // first log record of this level
+            const u32 snap_log = uni(ctl->log_count);          // first log record of this level
 #ifdef GP_DIAG
             const u64 lv_e0 = tk_expand, lv_s0 = tk_scan; u32 lv_passes = 0;
 #endif
@@ -1795,7 +1937,7 @@ __device__ __forceinline__ void gfpush_rows()
             // scanned only after its expansion succeeded).
             const bool bucketed = in_lds && parts >= kBucketMin && parts <= 64 &&
                                   (u64)e_cur + 1 <= p.bucket_cap;
-            bool use_buckets = !ctl->fail && bucketed;
+            bool use_buckets = bucketed && !uni(ctl->fail);
             if (use_buckets) {
 #ifdef GP_DIAG
                 u64 tkd[3] = {0, 0, 0};
@@ -1806,7 +1948,7 @@ __device__ __forceinline__ void gfpush_rows()
                 tk_expand += tkd[0]; tk_scan += tkd[1]; lv_passes += (u32)tkd[2];
 #endif
             }
-            if (!use_buckets && !ctl->fail) {
+            if (!use_buckets && !uni(ctl->fail)) {
                 {
                     u32 part = 0, np = parts;
                     for (;;) {
@@ -1826,8 +1968,8 @@ __device__ __forceinline__ void gfpush_rows()
                         }
                         GP_SYNC();
                         GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1); if (!in_lds) GP_ACCUM(tk_expand_hbm, t0, t1);
-                        if (ctl->fail) break;
-                        if (ctl->ovf) {
+                        if (uni(ctl->fail)) break;
+                        if (uni(ctl->ovf)) {
                             // this partition did not fit: wipe the table and split it in two
                             wipe_table<BLOCK>(lkeys, lvals, C);
                             GP_SYNC();
@@ -1850,7 +1992,7 @@ __device__ __forceinline__ void gfpush_rows()
                         }
                         GP_SYNC();
                         GP_STAMP(t2); GP_ACCUM(tk_scan, t1, t2); if (!in_lds) GP_ACCUM(tk_scan_hbm, t1, t2);
-                        if (ctl->fail) break;
+                        if (uni(ctl->fail)) break;
                         while (np > parts && (part & 1u)) { part >>= 1; np >>= 1; }   // right child done => parent done
                         ++part;
                         if (np == parts && part == parts) break;
@@ -1870,19 +2012,19 @@ __device__ __forceinline__ void gfpush_rows()
             }
 #endif
             {
-                const u32 lvl_len = ctl->log_count - snap_log;      // read after the level's last barrier
+                const u32 lvl_len = uni(ctl->log_count) - snap_log;      // read after the level's last barrier
                 n_levels = lvl + 1;
                 // first level with >= 2K records (early levels hold the LARGEST records: a stronger bound than the biggest level)
                 if (c > 0.0 && seg_len < 2u * (u32)p.K && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
             }
-            if (ctl->fail || !do_push) break;
-            n_push_cur = nx->n_push; n_long_cur = nx->n_long; e_cur = nx->e_next; e_short_cur = nx->e_short;
-            dang_cur = nx->dangling; has_dang_cur = nx->n_dangling != 0;
+            if (!do_push || uni(ctl->fail)) break;
+            n_push_cur = uni(nx->n_push); n_long_cur = uni(nx->n_long); e_cur = uni(nx->e_next);
+            has_dang_cur = uni(nx->n_dangling) != 0; dang_cur = has_dang_cur ? uni(nx->dangling) : 0.0;
             cur ^= 1;
         }
         GP_SYNC();
         {
-            const u32 failed = ctl->fail, n_log_row = ctl->log_count;      // one round trip
+            const u32 failed = uni(ctl->fail), n_log_row = uni(ctl->log_count);      // one round trip
             max_log = max(max_log, n_log_row);
             if (failed) {
                 // Leave the row unwritten.  Restore clean tables so that later rows of this workgroup are unaffected.
@@ -1903,7 +2045,7 @@ __device__ __forceinline__ void gfpush_rows()
 #endif
         phase_topk<BLOCK>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, seg_begin, seg_len, n_levels GP_SUB_ARGS);
         GP_SYNC();
-        if (ctl->fail) give_up();                                      // the candidate array overflowed: nothing was written
+        if (uni(ctl->fail)) give_up();                                      // the candidate array overflowed: nothing was written
         else if (tid < (int)sNumStats) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }      // the row is done: its counts count
         GP_STAMP(t1); GP_ACCUM(tk_topk, t0, t1);
         // top-K used the table region as scratch: restore the empty LDS table
@@ -1944,6 +2086,8 @@ __device__ __forceinline__ void gfpush_rows()
         __hip_atomic_fetch_add(&p.counters[kDiagX0 + 2], (u64)ctl->barn[tid >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) for (int i = 0; i < 4; ++i)
             __hip_atomic_fetch_add(&p.counters[kDiagX0 + 8 + i], ctl->scan_sub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) for (int i = 0; i < 8; ++i)
+            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 112 + i], ctl->exp_sub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (tid < 64 && ctl->site_n[tid]) {       // [128 + site] cycles waited at GP_SYNC() number `site` (source order), [192 + site] wave arrivals

@@ -86,7 +86,21 @@ def powerlaw_csr(n_nodes: int, samples: int, seed: int = 42, offset: int = 10):
 
 
 def shape_csr(name: str):
+    """The named shape.  GRANDPLUS_SYNTH_CACHE=<dir> keeps generated graphs as .npy files there (A/B tooling that
+    starts many processes on one box; e.g. /dev/shm/gp); without it every call regenerates."""
     s = SHAPES[name]
+    cache = os.environ.get("GRANDPLUS_SYNTH_CACHE")
+    if cache:
+        fp, fi = (os.path.join(cache, f"{name}_{s.seed}_{k}.npy") for k in ("indptr", "indices"))
+        if os.path.exists(fp) and os.path.exists(fi):
+            return np.load(fp), np.load(fi)
+        indptr, indices = powerlaw_csr(s.n_nodes, s.samples, s.seed, s.offset)
+        os.makedirs(cache, exist_ok=True)
+        for path, arr in ((fp, indptr), (fi, indices)):
+            tmp = f"{path}.{os.getpid()}.tmp.npy"
+            np.save(tmp, arr)
+            os.replace(tmp, path)
+        return indptr, indices
     return powerlaw_csr(s.n_nodes, s.samples, s.seed, s.offset)
 
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRANDPLUS_SYNTH_CACHE=${GRANDPLUS_SYNTH_CACHE:-/dev/shm/gp_synth}
 # A/B builds of the HIP library on the SAME GPU box (boxes differ by a few % in clocks):
 #   tools/ab.sh "liba.so libb.so ..." [workload ...]      (ROWS=16384 STEPS=3 by default)
 # Build the variants with tools/build_variant.sh <name> from the source state under test.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRANDPLUS_SYNTH_CACHE=${GRANDPLUS_SYNTH_CACHE:-/dev/shm/gp_synth}
 # A/B of (library, bench options) pairs on the SAME GPU box:  tools/ab_opts.sh "lib.so|--block-threads 1024 --lds-bytes 81920" "lib2.so|" -- mag reddit
 # ROWS=65536 STEPS=3 by default.
 PAIRS=(); while [ "$1" != "--" ] && [ -n "$1" ]; do PAIRS+=("$1"); shift; done; shift

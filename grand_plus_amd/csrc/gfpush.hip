@@ -46,10 +46,10 @@ int fail(int status, const char* fmt, ...) {
 // One set of per-workgroup scratch slabs (all caps are per workgroup).
 struct Slabs {
     int n_wg = 0;
-    u64 push_cap = 0, resg_cap = 0, log_cap = 0, cand_cap = 0, bucket_cap = 0;
-    PushEntry* push = nullptr; ResRec* resg = nullptr; ResRec* bucket = nullptr;
+    u64 push_cap = 0, resg_cap = 0, log_cap = 0, cand_cap = 0, bucket_cap = 0, bt_cap = 0;
+    PushEntry* push = nullptr; ResRec* resg = nullptr; ResRec* bucket = nullptr; u32* bt = nullptr;
     int* log_key = nullptr; double* log_val = nullptr; Cand* cand = nullptr;
-    size_t per_wg() const { return 16 * (size_t)(2 * push_cap + resg_cap + cand_cap + bucket_cap) + 12 * (size_t)log_cap + 64; }
+    size_t per_wg() const { return 16 * (size_t)(2 * push_cap + resg_cap + cand_cap + bucket_cap) + 12 * (size_t)log_cap + 8 * (size_t)bt_cap + 64; }
     size_t carve(char* p, int wgs) {                                   // lays the arrays out at p, returns the bytes used
         n_wg = wgs;
         char* q = p;
@@ -59,11 +59,12 @@ struct Slabs {
         bucket = (ResRec*)q;   q += 16 * (size_t)wgs * bucket_cap;
         log_val = (double*)q;  q += 8 * (size_t)wgs * log_cap;
         log_key = (int*)q;     q += 4 * (size_t)wgs * log_cap;
+        bt = (u32*)q;          q += 4 * (size_t)wgs * 2 * bt_cap;
         return ((size_t)(q - p) + 255) & ~(size_t)255;
     }
     bool covers(const Slabs& o) const {
         return n_wg >= o.n_wg && push_cap >= o.push_cap && resg_cap >= o.resg_cap && log_cap >= o.log_cap &&
-               cand_cap >= o.cand_cap && bucket_cap >= o.bucket_cap;
+               cand_cap >= o.cand_cap && bucket_cap >= o.bucket_cap && bt_cap >= o.bt_cap;
     }
 };
 
@@ -152,6 +153,8 @@ void free_workspace(Workspace& w) {
 //   F_max  = frontier size of one level    <= min(N, E_max) + 1          (+1: dangling -> seed)
 //   reserve-log records of a row           <= (L+1) * F_max
 //   support of the reserve map             <= min(N, 1 + L*F_max)
+double level_edge_bound_of(const gp_graph* g) { return (double)g->nnz + 16.0; }     // no level traverses more than every stored entry
+
 Slabs slab_sizes(const gp_graph* g, int n_coef, double e_max, double log_records) {
     const double n_d = (double)g->n_nodes;
     const double f_max = std::min(n_d, e_max) + 1.0;
@@ -163,7 +166,11 @@ Slabs slab_sizes(const gp_graph* g, int n_coef, double e_max, double log_records
     sl.resg_cap = (u64)std::max(2048.0, 2.0 * f_max);
     sl.log_cap = ((u64)logn + 3) & ~3ull;
     sl.cand_cap = (u64)supp + 1;
-    sl.push_cap = (u64)(f_max + e_max / kSplitLen + 2.0);
+    sl.push_cap = (u64)(f_max + 2.0);                        // one entry per pushing node
+    // one boundary-table word per 64 edges of a level.  Cheap (1/16 byte per edge), so it is sized well beyond the estimate:
+    // a level that outgrows e_max edges but not the entry / log capacities must not send its row to the retry launch
+    const double e_bt = std::min(level_edge_bound_of(g), std::max(8.0 * e_max, 1048576.0));
+    sl.bt_cap = (((u64)std::max(e_max, e_bt) >> kUnitShift) + 4) & ~1ull;
     sl.bucket_cap = (u64)e_max + 2;                 // (key, share) records of one bucketed level
     return sl;
 }
@@ -608,6 +615,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.out_row = d_row; kp.out_col = d_col; kp.out_val = d_val; kp.out_filled = d_filled;
     auto use_slabs = [&kp](const Slabs& sl) {
         kp.push = sl.push; kp.push_cap = sl.push_cap;
+        kp.bt = sl.bt; kp.bt_cap = sl.bt_cap;
         kp.resg = sl.resg; kp.resg_cap = sl.resg_cap;
         kp.log_key = sl.log_key; kp.log_val = sl.log_val; kp.log_cap = sl.log_cap;
         kp.cand = sl.cand; kp.cand_cap = sl.cand_cap;
@@ -622,9 +630,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.force_global = g->force_global;
     kp.prune = g->exact_stats ? 0 : 1;
     kp.diag_flags = g->diag_flags;
-    // short/long split of the push list: sparse shapes (mean degree <= 24: MAG-like, citation graphs) do better with
-    // 32 (+1.8 % on the MAG shape), denser ones with 64 (the Reddit shape loses 2 % at 32); tools/ab.sh sweep
-    kp.long_len = (g->nnz <= 24 * g->n_nodes) ? 32u : (u32)kLongLen;
+    kp.pad_ll = 0;
     // direct-indexed level tables: the whole graph fits the table of the 512-thread kernel (Cora, Citeseer)
     kp.direct = (block_threads == 512 && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0

@@ -5,7 +5,7 @@
 // seeds, precompute/graph.h:73-74).  Per row it runs the level-synchronous push of
 // graph.h:83-110 and the top-K of graph.h:111-126:
 //
-//   EXPAND  stream the CSR neighbour ranges of the push list, one lane per edge (flat_edges),
+//   EXPAND  stream the CSR neighbour ranges of the push list, one lane per edge, equal edge counts per wave (edge_stream),
 //           and add r/deg into the level's residue table          (graph.h:96-99).
 //   SCAN    drain that table; for every node u with residue r:
 //             reserve[u] += coef[lvl] * r   -> one (u, coef*r) record in the reserve LOG   (graph.h:90 / :109)
@@ -73,23 +73,19 @@ __device__ __forceinline__ double uni(double x) {
 }
 
 constexpr int    kEmpty      = -1;
-constexpr int    kSplitLen   = 128;     // a long CSR range is split into chunks of this many columns
-constexpr int    kLongLen    = 64;      // upper limit of KParams::long_len (ranges longer than long_len are expanded by a whole wave)
+constexpr u32    kUnitShift  = 6;       // EXPAND hands out a level's edges in units of 64 (one window; a step = up to 4 units)
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
-#ifndef GP_EXPAND_STREAM
-#define GP_EXPAND_STREAM 1       // EXPAND into LDS hash tables: the pipelined per-wave stream (expand_stream); 0 = the flat_edges form
-#endif
 #ifndef GP_FLAT_W
 #define GP_FLAT_W 4
 #endif
 constexpr int    kFlatW      = GP_FLAT_W;       // EXPAND: 64-edge windows a wave keeps in flight (column loads issued together)
 #ifdef GP_DIAG
-constexpr int    kCtlStruct  = 2048;    // (diagnostic build: + per-barrier-site wait counters)
+constexpr int    kCtlStruct  = 2048 + 64;    // (diagnostic build: + per-barrier-site wait counters)
 #else
 constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic LDS ...
 #endif
-constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (expand_flat)
+constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (edge_stream)
 #ifndef GP_MIN_CAP
 #define GP_MIN_CAP 1024
 #endif
@@ -110,7 +106,10 @@ constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many s
 constexpr u32    kProbeSpan  = kMaxProbe * (kMaxProbe + 1) / 2;   // furthest a triangular probe sequence can walk (300 slots)
                                         // (recoverable: the level / aggregation is redone in more partitions)
 
-struct PushEntry { int start; int len; double share; };  // 16 B
+// Push list of a level: one entry per pushing node, in the order of `off`.  The level's edges are numbered 0 .. E-1 in list
+// order; entry i covers edges [off_i, off_{i+1}) and edge q of it is column word rel + q of the CSR (rel = CSR start - off,
+// modulo 2^32).  No lengths, no chunking of hubs: EXPAND splits the EDGE range evenly over the waves, whatever the entries.
+struct PushEntry { u32 rel; u32 off; double share; };    // 16 B
 struct ResRec    { int key;   int pad; double val; };    // 16 B  residue table record (HBM)
 struct Cand      { u64 bits;  int key; int pad;  };      // 16 B  top-K candidate
 
@@ -119,11 +118,10 @@ struct Cand      { u64 bits;  int key; int pad;  };      // 16 B  top-K candidat
 struct LevelCtr {
     double dangling;      // mass returned to the seed by dangling nodes
     u32 n_dangling;       // how many dangling nodes were drained
-    u32 n_push;           // SHORT push-list entries (range length <= long_len), growing from the front
-    u32 n_long;           // LONG entries (chunks of <= kSplitLen), growing from the back of the same buffer
-    u32 e_short;          // edges covered by the short entries
-    u32 e_next;           // all edges the next EXPAND will traverse
-    u32 pad;
+    u32 pad0;
+    u64 alloc;            // next level's push list: entries so far (low half) and edges so far (high half) -- ONE atomic hands a wave
+                          // both its entry indices and its edge offsets, so the list is ordered by `off` however the waves interleave
+    u64 pad1;
 };
 
 // Control block (lives in LDS, one per workgroup).
@@ -150,7 +148,9 @@ struct Ctl {
 #ifdef GP_DIAG
     u64 barw[16];         // per wave: shader cycles spent waiting at workgroup barriers
     u32 barn[16];         // per wave: barriers passed
-    u64 exp_sub[8];       // wave 0: shader cycles in EXPAND (expand_stream): [0] prepare (edge -> entry, batch switches) [1] wait for the column loads [2] inserts [3] steps [4] batches [5] total [6] calls
+    u64 exp_c0, exp_c2, exp_pre, exp_post;   // wave 0: cycles from before the EXPAND call to the first instruction of edge_stream / from its last to behind the barrier
+    u32 exp_max, exp_pad; u64 exp_sum_max, exp_sum_all;   // per EXPAND call: longest wave / all waves (cycles), summed over calls
+    u64 exp_sub[8];       // wave 0: shader cycles in EXPAND (edge_stream): [0] prepare (edge -> entry) [1] wait for the column loads [2] inserts [3] steps [4] batches [5] total [6] calls
     u64 scan_sub[4];      // wave 0: shader cycles in SCAN's (a,b) compaction / (c) records / (d) lookups + push entries / tail
     u64 site_w[64];       // per GP_SYNC() site (in source order): shader cycles all waves waited there
     u32 site_n[64];       // per site: wave arrivals
@@ -159,6 +159,7 @@ struct Ctl {
 // Statistics live in LDS, not in registers: nine 64-bit per-thread counters alive for the whole kernel
 // cost 18 of the 128 VGPRs (spills).  Phases count in function-local registers and one lane per wave
 // adds the wave's totals here when the phase ends.
+static_assert(sizeof(Ctl) <= (size_t)kCtlStruct, "the control block must fit its LDS reservation");
 enum Stat { sPush = 0, sEdges, sFront, sDeg, sFilled, sSupport, sLds, sGlb, sFailed, sNumStats };
 __device__ __forceinline__ void stat_add(Ctl* ctl, int which, u64 n) {           // counts for the row in flight
     __hip_atomic_fetch_add(&ctl->st_row[which], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -238,6 +239,7 @@ struct KParams {
     const double* coef; int n_coef; double rmax; int K;
     int* out_row; int* out_col; double* out_val; int* out_filled;
     PushEntry* push; u64 push_cap;       // per-workgroup: 2 buffers of push_cap records (this level / next level)
+    u32* bt; u64 bt_cap;                  // per-workgroup: 2 boundary tables of bt_cap words: bt[m] = the push-list entry that contains edge 64 m
     ResRec* resg;    u64 resg_cap;       // per-workgroup HBM residue table
     int* log_key; double* log_val; u64 log_cap;   // per-workgroup reserve log
     Cand* cand;      u64 cand_cap;       // per-workgroup top-K candidates
@@ -246,7 +248,7 @@ struct KParams {
     u32 lds_slots;
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
-    u32 long_len;                         // CSR ranges up to this length are 'short' (G lanes per range), longer ones take a wave
+    u32 pad_ll;
     int direct;                           // 1: every level's table is indexed by node id (N <= lds_slots; 512-thread kernel only)
     // Two launches per call.  The first gives every workgroup a slab sized from an ESTIMATE of a row's needs; a row that
     // outgrows it is not failed but appended to retry_list.  The second launch (a few workgroups, slabs sized from the
@@ -279,7 +281,6 @@ __device__ __forceinline__ u32 slot_of(u32 h, u32 cap) { return (u32)(((u64)h * 
 // Home slot in an LDS table of `cap` slots.  Homes lie in [0, cap - kProbeSpan): a probe sequence then
 // never leaves [0, cap), so the probing loops need no wrap-around (4 VALU per probe); 2 % of a full
 // table is the price.  Every LDS table has cap >= kMinCap > kProbeSpan.
-static_assert(kFlatW == 4 || kFlatW == 8, "expand_flat clears its flags with one 32- or 64-bit store per lane");
 static_assert(kMinCap > 2 * kProbeSpan, "every LDS table must be much larger than the probe span");
 __device__ __forceinline__ u32 home_lds(u32 k, u32 cap) { return slot_of(hash_a(k), cap - kProbeSpan); }
 
@@ -529,6 +530,32 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
     return false;
 }
 
+// ---------------------------------------------------------------- push-list allocation
+// Appends the pushing nodes of one wave-step to the next level's push list.  Every lane of the wave must call (wave-uniform
+// control flow: DPP scan); a lane with len == 0 appends nothing.  ONE LDS atomic per call hands out entry indices and edge
+// offsets together; an entry that contains a multiple of 64 edges also records itself in the boundary table (read by
+// levels with more than 64 entries, see edge_stream).
+__device__ __forceinline__ void push_alloc(KP p, Ctl* ctl, LevelCtr* nx, PushEntry* push, u32* bt_g,
+                                           u32 len, u32 start, double share, int lane)
+{
+    const u64 M = __ballot(len != 0);
+    if (M == 0) return;                                                       // wave-uniform: nobody pushes
+    const u32 incl = wave_incl_scan_dpp(len);
+    const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    u64 base = 0;
+    if (lane == 0)
+        base = __hip_atomic_fetch_add(&nx->alloc, ((u64)tot << 32) | (u64)(u32)__popcll(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = uni(base);
+    if (len != 0) {
+        const u32 idx = (u32)base + lane_prefix(M), off = (u32)(base >> 32) + (incl - len);
+        if ((u64)idx < p.push_cap) { PushEntry pe; pe.rel = start - off; pe.off = off; pe.share = share; push[idx] = pe; }
+        else ctl->fail = 1;
+        for (u32 m = (off + (1u << kUnitShift) - 1u) >> kUnitShift; ((u64)m << kUnitShift) < (u64)off + len; ++m) {   // hubs: one word per 64 edges
+            if ((u64)m < p.bt_cap) bt_g[m] = idx; else ctl->fail = 1;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- SCAN (slot-walking form)
 // Drains the residue table of one level (or one partition of it).  U slots per thread are
 // handled per round so that the indptr loads of all U nodes are in flight together.
@@ -537,7 +564,7 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
 template <int BLOCK, bool IN_LDS, int U>
 __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                            ResRec* resg, u32 cap, int* log_key, double* log_val,
-                                           PushEntry* push, double c, bool do_push)
+                                           PushEntry* push, u32* bt_g, double c, bool do_push)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     u32 st_push = 0, st_edges = 0, st_front = 0, st_deg = 0;        // this thread, this level
@@ -598,12 +625,10 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
             }
         }
         if (!do_push) continue;
-        // (d) push decisions
-        bool is_short[U]; u32 n_long = 0, e_sum = 0, e_short = 0;
-        double share[U]; int len[U];
+        // (d) push decisions + push-list entries
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            share[u] = 0.0; len[u] = 0; is_short[u] = false;
+            double share = 0.0; u32 len = 0;
             if (want_deg[u]) {
                 const u32 deg = (u32)(de[u] - ds[u]);
                 if (deg == 0) {                                                      // graph.h:91-93
@@ -612,47 +637,10 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
                 } else if (r[u] >= p.rmax * (double)deg) {                           // graph.h:94
                     ++st_push; st_edges += deg;
                     const double sh = r[u] / (double)deg;                            // graph.h:95
-                    if (sh != 0.0) {
-                        share[u] = sh; len[u] = (int)deg;
-                        e_sum += deg;
-                        if (deg <= p.long_len) { is_short[u] = true; e_short += deg; }
-                        else n_long += (deg + kSplitLen - 1) / kSplitLen;
-                    }
+                    if (sh != 0.0) { share = sh; len = deg; }
                 }
             }
-        }
-        // (e) wave-level compaction of the push lists: short ranges fill the buffer from the
-        //     front, long-range chunks from the back
-        if (__ballot(e_sum != 0) == 0) continue;                  // wave-uniform: nobody pushes
-        u32 pi[U];
-        wave_alloc_flags<U>(&nx->n_push, is_short, pi, lane);
-        u32 qi = 0;
-        if (__ballot(n_long != 0) != 0) qi = wave_alloc(&nx->n_long, n_long, lane);   // hubs only
-        if (e_sum) {
-            __hip_atomic_fetch_add(&nx->e_next, e_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (e_short) __hip_atomic_fetch_add(&nx->e_short, e_short, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (len[u] == 0) continue;
-                if (is_short[u]) {
-                    // the two lists meet in the middle at worst: total entries <= push_cap by the host bound
-                    if ((u64)pi[u] + nx->n_long < p.push_cap) {
-                        PushEntry pe; pe.start = ds[u]; pe.len = len[u]; pe.share = share[u];
-                        push[pi[u]] = pe;
-                    } else ctl->fail = 1;
-                } else {
-                    for (int off = 0; off < len[u]; off += kSplitLen) {
-                        if ((u64)qi + nx->n_push < p.push_cap) {
-                            PushEntry pe;
-                            pe.start = ds[u] + off;
-                            pe.len = min(kSplitLen, len[u] - off);
-                            pe.share = share[u];
-                            push[p.push_cap - 1 - qi] = pe;
-                        } else ctl->fail = 1;
-                        ++qi;
-                    }
-                }
-            }
+            push_alloc(p, ctl, nx, push, bt_g, len, (u32)ds[u], share, lane);
         }
     }
     st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_front = wave_sum32(st_front); st_deg = wave_sum32(st_deg);
@@ -675,12 +663,11 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
 template <int BLOCK>
 __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                                  u32 cap, u32 C, int* log_key, double* log_val,
-                                                 PushEntry* push, double c, bool do_push)
+                                                 PushEntry* push, u32* bt_g, double c, bool do_push)
 {
     typedef int    i4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63;
-    u32 e_all = 0, e_sht = 0;                                       // edges of my pushes (all / short ranges)
     u32 st_push = 0, st_edges = 0, st_deg = 0;                      // this thread, this level
     // Every wave owns ONE contiguous range of the table (a multiple of 256 slots) per level: it first
     // compacts the whole range, then processes its nodes.  The steps of (c) each end in a wait for
@@ -785,7 +772,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 if (__ballot(want[v]) == 0) continue;                                     // wave-uniform
-                bool is_short = false; u32 n_long = 0; double share = 0.0; int len = 0;
+                double share = 0.0; u32 len = 0;
                 if (want[v]) {
                     const u32 deg = (u32)(de[v] - ds[v]);
                     if (deg == 0) {                                                       // graph.h:91-93
@@ -794,40 +781,10 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
                     } else if (r[v] >= p.rmax * (double)deg) {                            // graph.h:94
                         ++st_push; st_edges += deg;
                         const double sh = r[v] / (double)deg;                             // graph.h:95
-                        if (sh != 0.0) {
-                            share = sh; len = (int)deg;
-                            if (deg <= p.long_len) is_short = true;
-                            else n_long = (deg + kSplitLen - 1) / kSplitLen;
-                        }
+                        if (sh != 0.0) { share = sh; len = deg; }
                     }
                 }
-                if (__ballot(len != 0) == 0) continue;                                    // wave-uniform: nobody pushes
-                // push lists: short ranges fill the buffer from the front, long-range chunks from the back
-                const u32 pi = wave_alloc1(&nx->n_push, is_short, lane);
-                u32 qi = 0;
-                if (__ballot(n_long != 0) != 0) qi = wave_alloc(&nx->n_long, n_long, lane);   // hubs only
-                if (len != 0) {
-                    e_all += (u32)len;
-                    if (is_short) {
-                        e_sht += (u32)len;
-                        // the two lists meet in the middle at worst: total entries <= push_cap by the host bound
-                        if ((u64)pi + nx->n_long < p.push_cap) {
-                            PushEntry pe; pe.start = ds[v]; pe.len = len; pe.share = share;
-                            push[pi] = pe;
-                        } else ctl->fail = 1;
-                    } else {
-                        for (int off = 0; off < len; off += kSplitLen) {
-                            if ((u64)qi + nx->n_push < p.push_cap) {
-                                PushEntry pe;
-                                pe.start = ds[v] + off;
-                                pe.len = min(kSplitLen, len - off);
-                                pe.share = share;
-                                push[p.push_cap - 1 - qi] = pe;
-                            } else ctl->fail = 1;
-                            ++qi;
-                        }
-                    }
-                }
+                push_alloc(p, ctl, nx, push, bt_g, len, (u32)ds[v], share, lane);
             }
         }
     }
@@ -838,13 +795,8 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
     // atomics per step would serialise)
     if (lane == 0 && tot) stat_add(ctl, sFront, tot);
     if (do_push && tot) {
-        e_all = wave_sum32(e_all); e_sht = wave_sum32(e_sht);
         st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
         if (lane == 0) {
-            if (e_all) {
-                __hip_atomic_fetch_add(&nx->e_next, e_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (e_sht) __hip_atomic_fetch_add(&nx->e_short, e_sht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
             if (st_deg) stat_add(ctl, sDeg, st_deg);
             if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
         }
@@ -858,9 +810,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
 }
 
 // ---------------------------------------------------------------- EXPAND
-// Adds `share` into the next residue table for every column id of every push-list entry (graph.h:96-99): flat_edges
-// enumerates the edges one lane per edge, expand_flat inserts them.  With parts > 1 only targets of hash partition
-// `part` are kept (the others belong to a later pass over the same list).
+// Adds `share` into the next residue table for every column id of every push-list entry (graph.h:96-99).
 template <bool IN_LDS, bool DIRECT>
 __device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* resg, u32 cap, u32 node_mask, int v, double share, u32* flag) {
     if (DIRECT) { res_add_direct(lkeys, lvals, node_mask, v, share); return; }
@@ -868,207 +818,134 @@ __device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* r
     else if (!res_add_hbm(resg, cap, v, share)) *flag = 1u;
 }
 
-// EXPAND, flattened: ONE LANE PER EDGE.  A wave takes a batch of up to 64 consecutive push-list entries (lane j
-// owns entry j), prefix-sums their lengths, and walks the batch's T edges in windows of 64: lane i of a window
-// handles edge q = t + i, whatever entry it belongs to.  So every column load and every table insert runs with
-// all 64 lanes busy (the per-entry lane groups of round 1 sat at ~45 % because range lengths vary 1..32):
-// ~2.4x fewer wave-instructions per edge in a phase that is instruction-issue bound while it runs.
-// Edge -> entry: the entries starting inside the window flag their first edge in a per-wave byte array (LDS
-// operations of one wave execute in order: no barrier), a ballot turns the flags into a mask M, and the owner of
-// edge i is entry `first + popcount(M & lanes <= i)` -- mbcnt, no search.  The owner's (start - prefix, share)
-// are then pulled with ds_bpermute.  kFlatW windows are handled per step so that their column loads are in
-// flight together.
-// The edge enumeration of expand_flat, shared with the SCATTER of bucketed levels: calls f(v, share) with kFlatW
-// 64-edge windows per step (v[w] < 0 marks a lane past the end of the batch).
+// The edge enumeration of a level: ONE LANE PER EDGE, and every wave gets the same number of EDGES.
+//
+// The level's E edges are numbered in push-list order (PushEntry).  Wave w takes the 64-edge units [w U/W, (w+1) U/W) of the
+// U = ceil(E / 64) units and walks them in steps of up to four units = four 64-lane windows.  Lane j of the wave holds one
+// push-list entry; the owner of every edge of a step follows without a search: the entries that start inside the step flag
+// their first edge in a per-wave byte array (transposed: byte w of word `lane` = window w, so one ds_read_b32 fetches a lane's
+// four flags; LDS operations of one wave execute in order), a ballot turns each window's flags into a mask and the owner of
+// lane i's edge is entry first + popcount(flags up to i) -- mbcnt, no search; its (rel, share) arrive by ds_bpermute and the
+// column word is rel + q.  Which entries a lane holds:
+//   * a level of <= 64 entries (small levels, and levels made of a few hubs): every wave loads the WHOLE list once;
+//     `first` = the number of entries that start at or before the step's first edge, minus one (a ballot);
+//   * otherwise the boundary table tells where to start: bt[t / 64] = the entry that contains edge t, written by SCAN with
+//     the entries; the wave fetches the table words of all its steps with one load, and lane j of a step loads entry
+//     bt + j.  The rare step with more than 63 entries starting inside it continues in extra, unpipelined rounds.
+// What this replaces (round 2: one batch of <= 64 ENTRIES per wave, hubs cut into 128-column chunks on a second list): waves
+// got equal entry counts but unequal edge counts -- the longest wave of an EXPAND call took 1.45 x the mean -- and every batch
+// switch exposed the latency of its entry load (half of a wave's EXPAND time).
+//
+// The walk is a three-stage software pipeline: while the columns of step s are inserted (f), the column loads of step s+1 and
+// the entry load of step s+2 are in flight.  Every wait of an iteration sits at its top, so the loads issued behind it may
+// be conditional without the compiler's wait counts turning conservative; lanes without an edge load the sentinel word
+// indices[nnz] = -1 (all four column loads of a step are unconditional).  f(col[4], share[4]) is called once per step;
+// col < 0 = no edge.
 template <int BLOCK, class F>
-__device__ __forceinline__ void flat_edges(KP p, unsigned char* wscr, const PushEntry* list, long long stride_sign,
-                                           u32 n_entries, bool dry, F f)
-{
-    const int lane = threadIdx.x & 63;
-    constexpr u32 kWaves = BLOCK / 64;
-    constexpr int W = kFlatW;
-    const u32 wave = wave_id();
-    const u32 per = min(64u, (n_entries + kWaves - 1) / kWaves);         // entries per wave and round
-    for (u32 base = wave * per; base < n_entries; base += kWaves * per) {
-        const u32 cnt = min(per, n_entries - base);
-        int start = 0; u32 len = 0; double share = 0.0;
-        if ((u32)lane < cnt) {
-            const PushEntry pe = list[stride_sign * (long long)(base + (u32)lane)];
-            start = pe.start; len = (u32)pe.len; share = dry ? 0.0 : pe.share;   // dry: GP_DIAG's value-neutral second pass
-        }
-        const u32 incl = wave_incl_scan_dpp(len);
-        const u32 excl = incl - len;                                     // first edge of my entry inside the batch
-        const u32 T = (u32)__builtin_amdgcn_readlane((int)incl, 63);     // edges of the batch
-        const int rel = start - (int)excl;                               // column index of edge q = rel(owner) + q   graph.h:97
-        for (u32 t = 0; t < T; t += 64u * W) {
-            if (W == 4) *(u32*)(wscr + 4 * lane) = 0u;                   // clears the 64*W flags
-            else        *(u64*)(wscr + 8 * lane) = 0ull;
-            if (len != 0 && excl > t && excl < t + 64u * W) wscr[excl - t] = 1;
-            u32 before = (u32)__popcll(__ballot(len != 0 && excl <= t)) - 1u;    // owner of edge t (wave-uniform)
-            int v[W]; double sh[W];
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const bool mine = wscr[64 * w + lane] != 0;
-                const u64 M = __ballot(mine);
-                const u32 e = before + lane_prefix(M) + (mine ? 1u : 0u);        // lane that owns my edge
-                before += (u32)__popcll(M);
-                const int rel_e = __shfl(rel, (int)e);
-                sh[w] = __shfl(share, (int)e);
-                const u32 q = t + 64u * (u32)w + (u32)lane;
-                v[w] = q < T ? p.indices[rel_e + (int)q] : -1;                      // graph.h:97
-            }
-            f(v, sh);
-        }
-    }
-}
-
-template <int BLOCK, bool IN_LDS, bool DIRECT>
-__device__ __forceinline__ void expand_flat(KP p, u32* flag, unsigned char* wscr, int* lkeys, double* lvals, ResRec* resg, u32 cap,
-                                            const PushEntry* list, long long stride_sign, u32 n_entries,
-                                            u32 part, u32 parts, bool dry = false)
-{
-    constexpr int W = kFlatW;
-    flat_edges<BLOCK>(p, wscr, list, stride_sign, n_entries, dry, [&](const int (&v)[W], const double (&sh)[W]) {
-#ifdef GP_DIAG
-        if (dry && (p.diag_flags & 8)) {                     // timing attribution: the dry pass loads but does not insert
-#pragma unroll
-            for (int w = 0; w < W; ++w) if (v[w] == 0x7FFFFFFF) *flag = 1u;
-            return;
-        }
-#endif
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-            if (v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part))
-                res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v[w], sh[w], flag);   // graph.h:98
-    });
-}
-
-template <int BLOCK>
-__device__ __forceinline__ void expand_stream(KP p, Ctl* ctl, int* lkeys, double* lvals, u32 cap, const PushEntry* push,
-                                              u32 n_short, u32 n_long, u32 part, u32 parts, bool dry);
-template <int BLOCK, bool IN_LDS, bool DIRECT = false>
-__device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double* lvals,
-                                             ResRec* resg, u32 cap, const PushEntry* push,
-                                             u32 n_short, u32 n_long, u32 part, u32 parts, bool dry = false)
-{
-    u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
-    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave_id();
-    // hub chunks (<= kSplitLen columns each) grow from the back of the push buffer, the other ranges from its front
-#if GP_EXPAND_STREAM
-    if (IN_LDS && !DIRECT) { expand_stream<BLOCK>(p, ctl, lkeys, lvals, cap, push, n_short, n_long, part, parts, dry); return; }
-#endif
-    if (n_long)  expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push + (p.push_cap - 1), -1, n_long, part, parts, dry);
-    if (n_short) expand_flat<BLOCK, IN_LDS, DIRECT>(p, flag, wscr, lkeys, lvals, resg, cap, push, 1, n_short, part, parts, dry);
-}
-
-// ---------------------------------------------------------------- EXPAND into an LDS hash table: one pipelined stream per wave
-// Same edge enumeration as flat_edges (one lane per edge, windows of 64, four windows per step), restructured around what
-// the wave WAITS for.  A step of the old form was a chain of ~8 LDS round trips (flag byte, then three ds_bpermute, per
-// window), one HBM round trip for the column ids, and four serial probing chains -- roughly a third each of its ~5.5 k
-// cycles, with 32 of 80 VGPRs in use.  Here
-//   * the flags of a step's four windows lie transposed (byte w of word `lane`), so ONE ds_read_b32 fetches all four and
-//     the twelve ds_bpermute of the step issue back to back: two LDS round trips instead of eight;
-//   * the long (hub-chunk) and short entries of the wave form ONE stream of steps, and the column loads of step s+1 are
-//     issued BEFORE the inserts of step s (12 more live registers): the HBM latency of all but the first step of a stream
-//     is hidden behind the previous step's probing chains.
-template <int BLOCK>
-__device__ __forceinline__ void expand_stream(KP p, Ctl* ctl, int* lkeys, double* lvals, u32 cap, const PushEntry* push,
-                                              u32 n_short, u32 n_long, u32 part, u32 parts, bool dry)
+__device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* push, const u32* bt,
+                                            u32 n_ent, u32 E, bool dry, F f)
 {
     constexpr u32 kWaves = BLOCK / 64;
-    static_assert(kFlatW == 4, "expand_stream reads the four window flags of a lane as one 32-bit word");
+    static_assert(kFlatW == 4, "edge_stream reads the four window flags of a lane as one 32-bit word");
     const u32 lane = threadIdx.x & 63u;
     const u32 wave = wave_id();
     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave;
-    u32* flag = &ctl->ovf;
     const int* indices = p.indices;
-    const u32 per_l = min(64u, (n_long + kWaves - 1) / kWaves), per_s = min(64u, (n_short + kWaves - 1) / kWaves);
-    const PushEntry* long0 = push + (p.push_cap - 1);
-    // the wave's position in its stream: list (0 = long chunks, from the back of the buffer; 1 = short ranges), next batch, next step
-    u32 which = 0, base = wave * per_l;
-    int rel = 0; u32 len = 0, excl = 0, T = 0, t = 0; double share = 0.0;
-
+    const u32 sentinel = (u32)p.nnz;
+#ifdef GP_DIAG
+    if (threadIdx.x == 0) { const u64 c1_ = clock64(); ctl->exp_pre += c1_ - ctl->exp_c0; ctl->exp_c2 = c1_; }
+#endif
+    const u32 units = (E + (1u << kUnitShift) - 1u) >> kUnitShift;
+    // (ranges are dealt from the last wave down, so that a level of a few units lands on wave 0, 1, ...: the waves that were
+    //  dispatched first win the issue arbitration against younger waves, and a small level is a latency chain of one wave)
+    const u32 slot = kWaves - 1u - wave;
+    const u32 u_lo = (u32)(((u64)slot * units) / kWaves), u_hi = (u32)(((u64)(slot + 1) * units) / kWaves);
+    if (u_lo >= u_hi || n_ent == 0) return;
+    const bool small = n_ent <= 64u;                                           // (wave-uniform) the whole list in one wave
 #ifdef GP_DIAG
     u64 xs[7] = {0, 0, 0, 0, 0, 0, 1}; u64 x0 = clock64(), xa = x0, xb;
 #define GP_XS(i) do { xb = clock64(); xs[i] += xb - xa; xa = xb; } while (0)
-#define GP_XS_FLUSH() do { xs[5] = clock64() - x0; if (threadIdx.x == 0) for (int i_ = 0; i_ < 7; ++i_) ctl->exp_sub[i_] += xs[i_]; } while (0)
+#define GP_XS_FLUSH() do { xs[5] = clock64() - x0; if (threadIdx.x == 0) { for (int i_ = 0; i_ < 7; ++i_) ctl->exp_sub[i_] += xs[i_]; ctl->exp_c2 = clock64(); } \
+    if ((threadIdx.x & 63) == 0) { __hip_atomic_fetch_max(&ctl->exp_max, (u32)xs[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&ctl->exp_sum_all, xs[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } } while (0)
 #else
 #define GP_XS(i) do { } while (0)
 #define GP_XS_FLUSH() do { } while (0)
 #endif
-    // Prepares the next step of the stream: the element index of every lane's column word (lanes past the end of the batch,
-    // and every lane once the stream has ended, get the sentinel word indices[nnz] = -1) and the share of its entry.
-    // Returns false once the stream has ended.
-    auto prepare = [&](u32 (&idx)[4], double (&sh)[4]) -> bool {
-        bool live = true;
-        while (t >= T) {                                                       // next batch of <= 64 entries (wave-uniform)
-            if (which == 0 && base >= n_long) { which = 1; base = wave * per_s; }
-            if (which == 1 && base >= n_short) { live = false; break; }
-            const u32 n = which == 0 ? n_long : n_short, per = which == 0 ? per_l : per_s;
-            const u32 cnt = min(per, n - base);
-            int start = 0; len = 0; share = 0.0;
-            if (lane < cnt) {
-                const PushEntry pe = which == 0 ? long0[-(long long)(base + lane)] : push[base + lane];
-                start = pe.start; len = (u32)pe.len; share = dry ? 0.0 : pe.share;
-            }
-            base += kWaves * per;
-            const u32 incl = wave_incl_scan_dpp(len);
-            excl = incl - len;                                                 // first edge of my entry inside the batch
-            T = (u32)__builtin_amdgcn_readlane((int)incl, 63);                 // edges of the batch
-            rel = start - (int)excl;                                           // column index of edge q = rel(owner) + q   graph.h:97
-            t = 0;
-#ifdef GP_DIAG
-            xs[4] += 1;
-#endif
-        }
-        if (!live) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { idx[w] = (u32)p.nnz; sh[w] = 0.0; }
-            return false;
-        }
-        // edge -> entry: entries that start inside the step flag their first edge (LDS operations of one wave execute in order)
-        *(u32*)(wscr + 4 * lane) = 0u;
-        if (len != 0 && excl > t && excl < t + 256u) { const u32 pos = excl - t; wscr[(pos & 63u) * 4u + (pos >> 6)] = 1; }
-        asm volatile("" ::: "memory");        // the word is written by OTHER lanes: without this the compiler forwards this lane's own 0
-        const u32 f = *(const u32*)(wscr + 4 * lane);
-        u32 before = (u32)__popcll(__ballot(len != 0 && excl <= t)) - 1u;      // owner of edge t (wave-uniform)
-        u32 e[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const bool mine = ((f >> (8 * w)) & 1u) != 0;
-            const u64 M = __ballot(mine);
-            e[w] = (before + lane_prefix(M) + (mine ? 1u : 0u)) << 2;          // byte address of the owning lane for ds_bpermute
-            before += (u32)__popcll(M);
-        }
-        const u64 sbits = (u64)__double_as_longlong(share);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int rel_e = __builtin_amdgcn_ds_bpermute((int)e[w], rel);
-            const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)e[w], (int)(u32)sbits);
-            const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)e[w], (int)(u32)(sbits >> 32));
-            const u32 q = t + 64u * (u32)w + lane;
-            idx[w] = q < T ? (u32)(rel_e + (int)q) : (u32)p.nnz;
-            sh[w] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
-        }
-        t += 256u;
-        return true;
+    // boundary-table words of this wave's regular steps (lane j: step j of the current group of 64 steps)
+    u32 btv = 0, bt_first = 0;
+    auto load_bt = [&](u32 step0) {
+        const u32 uj = u_lo + 4u * (step0 + lane);
+        btv = uj < u_hi ? bt[uj] : 0u;
+        bt_first = step0;
     };
-    // One loop, one basic block per iteration behind the batch switch: prepare step s+1 (LDS only), take over the columns
-    // of step s (their loads have been in flight since the previous iteration), issue the loads of step s+1, insert step s.
-    // The loads are unconditional (a finished stream loads the sentinel word once more), so nothing between "issue" and
-    // "consume" merges control flow and the compiler's wait counts stay exact.
-    int nc[4]; double ns[4];
-    {
-        u32 idx[4];
-        if (!prepare(idx, ns)) { GP_XS_FLUSH(); return; }
-        GP_XS(0);
+    if (!small) load_bt(0);
+
+    // Pipeline registers.  "Next" = the step whose entries are in flight: lane j holds entry i0n + j (the whole list when
+    // `small`), to be matched against the edges [t0n, t1n).
+    PushEntry entn; entn.rel = 0; entn.off = 0; entn.share = 0.0;
+    u32 i0n = 0, t0n = 0, t1n = 0;
+    u32 u_next = u_lo;                       // first unit of the next REGULAR step (a step normally starts at a multiple of 4 units)
+    bool have_ent = true;
+    // Stage A: issue the entry load of the step that follows.  `end` < t1n: more than 63 entries start inside the step just
+    // matched -- its remainder [end, t1n) is the next step, with the entries from i0n + 63 on (lane 63 of a full round only bounds it).
+    auto fetch_next = [&](u32 end) {
+        if (end < t1n) { i0n += 63u; t0n = end; }
+        else if (u_next < u_hi) {
+            t0n = u_next << kUnitShift; t1n = min(E, min(u_next + 4u, u_hi) << kUnitShift);
+            if (!small) {
+                const u32 s_no = (u_next - u_lo) >> 2;
+                if (s_no - bt_first >= 64u) load_bt(s_no);
+                i0n = (u32)__builtin_amdgcn_readlane((int)btv, (int)(s_no - bt_first));
+            }
+            u_next += 4u;
+        } else { have_ent = false; return; }
+        if (!small) entn = push[min(i0n + lane, n_ent - 1u)];
+    };
+    if (small) entn = push[min(lane, n_ent - 1u)];
+    fetch_next(0);                           // t0n = t1n = 0: takes the regular branch
+
+    int nc[4] = {-1, -1, -1, -1}; double ns[4] = {0.0, 0.0, 0.0, 0.0};     // columns in flight and their shares
+    bool have_cols = false;
+    // One loop: match the next step's edges to its entries (LDS only), take over the columns of the step before (their loads
+    // have been in flight since the previous iteration), issue the next step's column loads and the entry load of the step
+    // after it, insert.  Every wait of an iteration sits at its top, so the loads issued behind may be conditional.
+    do {
+        u32 idx[4]; double sh[4]; u32 end = 0;
+        if (have_ent) {
+            // edge -> entry for the edges [t0n, t1n) given the entries from i0n on
+            const u32 cnt = min(64u, n_ent - i0n);
+            const u32 off = lane < cnt ? entn.off : 0xFFFFFFFFu;
+            end = t1n;
+            if (cnt == 64u && i0n + 64u < n_ent) {                             // the 64th entry only bounds the round (wave-uniform)
+                const u32 o63 = (u32)__builtin_amdgcn_readlane((int)off, 63);
+                if (o63 < t1n) end = o63;
+            }
+            *(u32*)(wscr + 4 * lane) = 0u;
+            if (off > t0n && off < end) { const u32 pos = off - t0n; wscr[(pos & 63u) * 4u + (pos >> 6)] = 1; }
+            asm volatile("" ::: "memory");    // the word is written by OTHER lanes: without this the compiler forwards this lane's own 0
+            const u32 fl = *(const u32*)(wscr + 4 * lane);
+            // the entry that contains edge t0n: lane 0's when the boundary table (or a continuation) chose i0n, else the last
+            // one that starts at or before t0n
+            u32 before = small ? (u32)__popcll(__ballot(off <= t0n)) - 1u : 0u;
+            u32 e[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) nc[w] = indices[idx[w]];                   // graph.h:97
-    }
-    bool live = true;
-    while (live) {
-        u32 idx[4]; double sh[4];
-        live = prepare(idx, sh);
+            for (int w = 0; w < 4; ++w) {
+                const bool mine = ((fl >> (8 * w)) & 1u) != 0;
+                const u64 M = __ballot(mine);
+                e[w] = (before + lane_prefix(M) + (mine ? 1u : 0u)) << 2;      // byte address of the owning lane for ds_bpermute
+                before += (u32)__popcll(M);
+            }
+            const u64 sbits = (u64)__double_as_longlong(dry ? 0.0 : entn.share);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)e[w], (int)entn.rel);
+                const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)e[w], (int)(u32)sbits);
+                const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)e[w], (int)(u32)(sbits >> 32));
+                const u32 q = t0n + 64u * (u32)w + lane;
+                idx[w] = q < end ? rel_e + q : sentinel;                       // graph.h:97
+                sh[w] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+            }
+        }
         GP_XS(0);
         int cc[4]; double cs[4];
 #pragma unroll
@@ -1077,15 +954,33 @@ __device__ __forceinline__ void expand_stream(KP p, Ctl* ctl, int* lkeys, double
         if (cc[0] == 0x7FFFFFF0 && cc[1] == 0x7FFFFFF0 && cc[2] == 0x7FFFFFF0 && cc[3] == 0x7FFFFFF0) xs[6] += 1;      // (uses the loaded values: the wait is charged here)
         GP_XS(1); xs[3] += 1;
 #endif
+        const bool had_cols = have_cols;
+        have_cols = have_ent;
+        if (have_ent) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; ns[w] = sh[w]; }
+            for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; ns[w] = sh[w]; }
+            fetch_next(end);
+        }
+        if (had_cols) f(cc, cs);
+        GP_XS(2);
+    } while (have_cols);
+    GP_XS_FLUSH();
+}
+
+// MODE 0: LDS hash table, 1: HBM table, 2: direct-indexed LDS table.  With parts > 1 only targets of hash partition
+// `part` are kept (the others belong to a later pass over the same list).
+template <int BLOCK, bool IN_LDS, bool DIRECT = false>
+__device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double* lvals,
+                                             ResRec* resg, u32 cap, const PushEntry* push, const u32* bt,
+                                             u32 n_ent, u32 E, u32 part, u32 parts, bool dry = false)
+{
+    u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
+    edge_stream<BLOCK>(p, ctl, push, bt, n_ent, E, dry, [&](const int (&v)[4], const double (&sh)[4]) {
 #pragma unroll
         for (int w = 0; w < 4; ++w)
-            if (cc[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)cc[w]), parts) == part))
-                res_add_lds_flag(lkeys, lvals, cap, cc[w], cs[w], flag);      // graph.h:98
-        GP_XS(2);
-    }
-    GP_XS_FLUSH();
+            if (v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part))
+                res_add_any<IN_LDS, DIRECT>(lkeys, lvals, resg, cap, p.node_mask, v[w], sh[w], flag);   // graph.h:98
+    });
 }
 
 // ---------------------------------------------------------------- bucketed levels
@@ -1551,7 +1446,7 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
 // and the start of dynamic LDS.
 struct WgView {
     Ctl* ctl; double* lvals; int* lkeys; u32 C;
-    PushEntry* push2; ResRec* resg; int* log_key; double* log_val; Cand* cand; ResRec* bucket;
+    PushEntry* push2; ResRec* resg; int* log_key; double* log_val; Cand* cand; ResRec* bucket; u32* bt2;
 };
 __device__ __forceinline__ WgView wg_view(KP p, u32 lds0) {
     WgView w;
@@ -1566,25 +1461,27 @@ __device__ __forceinline__ WgView wg_view(KP p, u32 lds0) {
     w.log_val = p.log_val + wg * p.log_cap;
     w.cand    = p.cand + wg * p.cand_cap;
     w.bucket  = p.bucket + wg * p.bucket_cap;
+    w.bt2     = p.bt + wg * 2 * p.bt_cap;
     return w;
 }
 #ifdef GP_DIAG
-#define GP_PHASE_NOINLINE __attribute__((noinline))
+#define GP_PHASE_NOINLINE static __attribute__((noinline))
 #else
-#define GP_PHASE_NOINLINE __attribute__((noinline))
+#define GP_PHASE_NOINLINE static __attribute__((noinline))
 #endif
 
 // EXPAND of one level (or one hash partition of it).  MODE 0: LDS hash table, 1: HBM table, 2: direct-indexed LDS table.
 template <int BLOCK, int MODE>
-__device__ GP_PHASE_NOINLINE void phase_expand(u32 lds0, u32 cap, u32 cur, u32 n_short, u32 n_long, u32 part, u32 np,
+__device__ GP_PHASE_NOINLINE void phase_expand(u32 lds0, u32 cap, u32 cur, u32 n_ent, u32 E, u32 part, u32 np,
                                                u32 has_dang, double dang, int seed_key, u32 dry)
 {
     KP p = kparams();
-    lds0 = uni(lds0); cap = uni(cap); cur = uni(cur); n_short = uni(n_short); n_long = uni(n_long); part = uni(part); np = uni(np);
+    lds0 = uni(lds0); cap = uni(cap); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); part = uni(part); np = uni(np);
     has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); dry = uni(dry);
     const WgView w = wg_view(p, lds0);
     const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
-    expand_level<BLOCK, MODE != 1, MODE == 2>(p, w.ctl, w.lkeys, w.lvals, w.resg, cap, push_cur, n_short, n_long, part, np, dry != 0);
+    expand_level<BLOCK, MODE != 1, MODE == 2>(p, w.ctl, w.lkeys, w.lvals, w.resg, cap, push_cur, w.bt2 + (size_t)cur * p.bt_cap,
+                                              n_ent, E, part, np, dry != 0);
     if (threadIdx.x == 0 && has_dang && !dry) {                                                    // graph.h:92
         if (MODE == 2) res_add_direct(w.lkeys, w.lvals, p.node_mask, seed_key, dang);
         else if (np == 1 || slot_of(hash_b((u32)seed_key), np) == part) {
@@ -1604,7 +1501,7 @@ __device__ GP_PHASE_NOINLINE void phase_scan_dense(u32 lds0, u32 cap, u32 nx_sel
     lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); c = uni(c); do_push = uni(do_push);
     const WgView w = wg_view(p, lds0);
     scan_level_dense<BLOCK>(p, w.ctl, &w.ctl->lc[nx_sel], w.lkeys, w.lvals, cap, w.C, w.log_key, w.log_val,
-                            w.push2 + (size_t)nxt_sel * p.push_cap, c, do_push != 0);
+                            w.push2 + (size_t)nxt_sel * p.push_cap, w.bt2 + (size_t)nxt_sel * p.bt_cap, c, do_push != 0);
 }
 template <int BLOCK>
 __device__ GP_PHASE_NOINLINE void phase_scan_hbm(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, double c, u32 do_push)
@@ -1613,7 +1510,7 @@ __device__ GP_PHASE_NOINLINE void phase_scan_hbm(u32 lds0, u32 cap, u32 nx_sel, 
     lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); c = uni(c); do_push = uni(do_push);
     const WgView w = wg_view(p, lds0);
     scan_level<BLOCK, false, 4>(p, w.ctl, &w.ctl->lc[nx_sel], w.lkeys, w.lvals, w.resg, cap, w.log_key, w.log_val,
-                                w.push2 + (size_t)nxt_sel * p.push_cap, c, do_push != 0);
+                                w.push2 + (size_t)nxt_sel * p.push_cap, w.bt2 + (size_t)nxt_sel * p.bt_cap, c, do_push != 0);
 }
 
 // The empty LDS table (start of the kernel, after TOP-K used the region as scratch, after an overflowing partition).
@@ -1636,11 +1533,11 @@ __device__ __forceinline__ void wipe_table(int* lkeys, double* lvals, u32 C) {
 // fixed-stride per-bucket runs (one lane per edge, like EXPAND), then one insert pass + SCAN per bucket.  Returns 0 when a
 // bucket run overflowed (a hub collected the level's edges): the caller then takes the hash-partition walk.
 template <int BLOCK>
-__device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, u32 cur, u32 n_short, u32 n_long,
+__device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, u32 cur, u32 n_ent, u32 E,
                                                       u32 has_dang, double dang, int seed_key, u32 nx_sel, double c, u32 do_push GP_TK_PARAMS)
 {
     KP p = kparams();
-    lds0 = uni(lds0); cap = uni(cap); P = uni(P); cur = uni(cur); n_short = uni(n_short); n_long = uni(n_long);
+    lds0 = uni(lds0); cap = uni(cap); P = uni(P); cur = uni(cur); n_ent = uni(n_ent); E = uni(E);
     has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); nx_sel = uni(nx_sel); c = uni(c); do_push = uni(do_push);
     const WgView w = wg_view(p, lds0);
     Ctl* ctl = w.ctl;
@@ -1658,21 +1555,18 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
     if (tid == 0) ctl->bovf = 0;
     GP_SYNC();
     GP_STAMP(t0);
-    {   // one lane per edge, like EXPAND
-        unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave_id();
-        auto scatter = [&](const int (&v)[kFlatW], const double (&sh)[kFlatW]) {
+    // one lane per edge, like EXPAND
+    edge_stream<BLOCK>(p, ctl, push_cur, w.bt2 + (size_t)cur * p.bt_cap, n_ent, E, false,
+                       [&](const int (&v)[4], const double (&sh)[4]) {
 #pragma unroll
-            for (int q = 0; q < kFlatW; ++q) {
-                if (v[q] < 0) continue;
-                const u32 bk = slot_of(hash_b((u32)v[q]), P);
-                const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (i < stride) { ResRec r; r.key = v[q]; r.pad = 0; r.val = sh[q]; bucket[(u64)bk * stride + i] = r; }
-                else ctl->bovf = 1;
-            }
-        };
-        if (n_long)  flat_edges<BLOCK>(p, wscr, push_cur + (p.push_cap - 1), -1, n_long, false, scatter);
-        if (n_short) flat_edges<BLOCK>(p, wscr, push_cur, 1, n_short, false, scatter);
-    }
+        for (int q = 0; q < 4; ++q) {
+            if (v[q] < 0) continue;
+            const u32 bk = slot_of(hash_b((u32)v[q]), P);
+            const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (i < stride) { ResRec r; r.key = v[q]; r.pad = 0; r.val = sh[q]; bucket[(u64)bk * stride + i] = r; }
+            else ctl->bovf = 1;
+        }
+    });
     GP_SYNC();
     GP_STAMP(t1); GP_TK_ACC(0, t0, t1);
     if (ctl->bovf) return 0u;
@@ -1781,6 +1675,7 @@ __device__ __forceinline__ void gfpush_rows()
     if (tid < 16) { ctl->barw[tid] = 0; ctl->barn[tid] = 0; }
     if (tid < 4) ctl->scan_sub[tid] = 0;
     if (tid < 8) ctl->exp_sub[tid] = 0;
+    if (tid == 0) { ctl->exp_max = 0; ctl->exp_sum_max = 0; ctl->exp_sum_all = 0; ctl->exp_pre = 0; ctl->exp_post = 0; ctl->exp_c0 = 0; ctl->exp_c2 = 0; }
     if (tid < 64) { ctl->site_w[tid] = 0; ctl->site_n[tid] = 0; }
     const u64 wave_t0 = clock64();
 #endif
@@ -1831,14 +1726,14 @@ __device__ __forceinline__ void gfpush_rows()
         if (tid == 0 && seed_deg != 0xFFFFFFFFu) rs1 = wall_clock64();     // after the queue -> seed -> indptr chain
 #endif
         // state of the level about to be produced: its push list (built by the previous SCAN)
-        u32 n_push_cur = 0, n_long_cur = 0, e_cur = 0;
+        u32 n_ent_cur = 0, e_cur = 0;
         u32 seg_begin = 0, seg_len = 0; int n_levels = 0;     // biggest level of the reserve log (coef > 0)
         double dang_cur = 0.0;
         bool has_dang_cur = false;
         int cur = 0;
 
         // ---- level 0 without a table: the frontier is { seed : 1.0 } (graph.h:81), so its reserve
-        //      record, its push test and its push-list entries are written directly.  This removes one
+        //      record, its push test and its push-list entry are written directly.  This removes one
         //      EXPAND/SCAN round trip (two barriers, a table walk and a dependent indptr load) per row.
         {
             const double c0 = uni(p.coef[0]);
@@ -1858,30 +1753,22 @@ __device__ __forceinline__ void gfpush_rows()
                     const double share = 1.0 / (double)seed_deg;                      // graph.h:95
                     if (tid == 0) { stat_add(ctl, sPush, 1); stat_add(ctl, sEdges, seed_deg); }
                     if (share != 0.0) {
-                        e_cur = seed_deg;
-                        if (seed_deg <= p.long_len) {
-                            n_push_cur = 1;
-                            if (tid == 0) {
-                                if (p.push_cap > 0) { PushEntry pe; pe.start = (int)s_start; pe.len = (int)seed_deg; pe.share = share; push_nxt0[0] = pe; }
-                                else ctl->fail = 1;
-                            }
-                        } else {
-                            n_long_cur = (seed_deg + kSplitLen - 1) / kSplitLen;
-                            if ((u64)n_long_cur > p.push_cap) { if (tid == 0) ctl->fail = 1; }
-                            else
-                                for (u32 q = (u32)tid; q < n_long_cur; q += BLOCK) {
-                                    PushEntry pe;
-                                    pe.start = (int)(s_start + q * (u32)kSplitLen);
-                                    pe.len = (int)min((u32)kSplitLen, seed_deg - q * (u32)kSplitLen);
-                                    pe.share = share;
-                                    push_nxt0[p.push_cap - 1 - q] = pe;
-                                }
+                        e_cur = seed_deg; n_ent_cur = 1;
+                        if (tid == 0) {
+                            if (p.push_cap > 0) { PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push_nxt0[0] = pe; }
+                            else ctl->fail = 1;
                         }
+                        // the one entry contains every 64-edge boundary of the level (a hub seed: many)
+                        const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
+                        u32* bt_g = w.bt2 + (size_t)1 * p.bt_cap;
+                        if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
+                        else
+                            for (u32 m = (u32)tid; m < units; m += BLOCK) bt_g[m] = 0u;
                     }
                 }
             }
             cur = 1;
-            GP_SYNC();                            // push entries / fail flag visible to every wave
+            GP_SYNC();                            // push entry / boundary table / fail flag visible to every wave
         }
 #ifdef GP_DIAG
         GP_STAMP(rs2);
@@ -1923,8 +1810,7 @@ __device__ __forceinline__ void gfpush_rows()
             // now, and SCAN only starts after the end-of-EXPAND barrier.  No barrier needed here.
             LevelCtr* nx = &ctl->lc[lvl & 1];
             if (tid == 0) {
-                nx->dangling = 0.0; nx->n_dangling = 0; nx->n_push = 0; nx->n_long = 0;
-                nx->e_short = 0; nx->e_next = 0;
+                nx->dangling = 0.0; nx->n_dangling = 0; nx->alloc = 0ull;
             }
             if (!in_lds) {
                 parts = 1;
@@ -1942,7 +1828,7 @@ __device__ __forceinline__ void gfpush_rows()
 #ifdef GP_DIAG
                 u64 tkd[3] = {0, 0, 0};
 #endif
-                use_buckets = phase_bucketed_level<BLOCK>(lds0, cap, parts, (u32)cur, n_push_cur, n_long_cur, has_dang_cur ? 1u : 0u, dang_cur,
+                use_buckets = phase_bucketed_level<BLOCK>(lds0, cap, parts, (u32)cur, n_ent_cur, e_cur, has_dang_cur ? 1u : 0u, dang_cur,
                                                           seed_key, (u32)(lvl & 1), c, do_push ? 1u : 0u GP_TK_ARGS) != 0;
 #ifdef GP_DIAG
                 tk_expand += tkd[0]; tk_scan += tkd[1]; lv_passes += (u32)tkd[2];
@@ -1955,18 +1841,22 @@ __device__ __forceinline__ void gfpush_rows()
                         GP_STAMP(t0);
 #ifdef GP_DIAG
                         ++lv_passes;
+                        if (tid == 0) ctl->exp_c0 = clock64();
 #endif
                         if (BLOCK == 512 && direct) {
-                            phase_expand<BLOCK, BLOCK == 512 ? 2 : 0>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
+                            phase_expand<BLOCK, BLOCK == 512 ? 2 : 0>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
                         } else if (in_lds) {
-                            phase_expand<BLOCK, 0>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
+                            phase_expand<BLOCK, 0>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
 #ifdef GP_DIAG
-                            if (p.diag_flags & 2) phase_expand<BLOCK, 0>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, 0u, 0.0, seed_key, 1u);
+                            if (p.diag_flags & 2) phase_expand<BLOCK, 0>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, 0u, 0.0, seed_key, 1u);
 #endif
                         } else {
-                            phase_expand<BLOCK, 1>(lds0, cap, (u32)cur, n_push_cur, n_long_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
+                            phase_expand<BLOCK, 1>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
                         }
                         GP_SYNC();
+#ifdef GP_DIAG
+                        if (tid == 0) { ctl->exp_sum_max += ctl->exp_max; ctl->exp_max = 0; ctl->exp_post += clock64() - ctl->exp_c2; }
+#endif
                         GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1); if (!in_lds) GP_ACCUM(tk_expand_hbm, t0, t1);
                         if (uni(ctl->fail)) break;
                         if (uni(ctl->ovf)) {
@@ -2007,7 +1897,7 @@ __device__ __forceinline__ void gfpush_rows()
                 __hip_atomic_fetch_add(dx + 1, tk_scan - lv_s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(dx + 2, (u64)e_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(dx + 3, (u64)(ctl->log_count - snap_log), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dx + 4, (u64)(n_push_cur + n_long_cur), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dx + 4, (u64)n_ent_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(dx + 5, (u64)lv_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #endif
@@ -2018,7 +1908,7 @@ __device__ __forceinline__ void gfpush_rows()
                 if (c > 0.0 && seg_len < 2u * (u32)p.K && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
             }
             if (!do_push || uni(ctl->fail)) break;
-            n_push_cur = uni(nx->n_push); n_long_cur = uni(nx->n_long); e_cur = uni(nx->e_next);
+            { const u64 al = uni(nx->alloc); n_ent_cur = (u32)al; e_cur = (u32)(al >> 32); }
             has_dang_cur = uni(nx->n_dangling) != 0; dang_cur = has_dang_cur ? uni(nx->dangling) : 0.0;
             cur ^= 1;
         }
@@ -2088,6 +1978,12 @@ __device__ __forceinline__ void gfpush_rows()
             __hip_atomic_fetch_add(&p.counters[kDiagX0 + 8 + i], ctl->scan_sub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) for (int i = 0; i < 8; ++i)
             __hip_atomic_fetch_add(&p.counters[kDiagX0 + 112 + i], ctl->exp_sub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 120], ctl->exp_sum_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 121], ctl->exp_sum_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 122], ctl->exp_pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 123], ctl->exp_post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     if (tid < 64 && ctl->site_n[tid]) {       // [128 + site] cycles waited at GP_SYNC() number `site` (source order), [192 + site] wave arrivals

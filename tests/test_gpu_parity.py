@@ -210,7 +210,7 @@ def test_partitioned_levels_small_lds():
     r = RECIPES[("reddit", "avg")]
     base, st0 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, r.top_k)
     small, st1 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, r.top_k,
-                          options={"block_threads": 256, "lds_bytes": 40960, "exact_stats": 1})
+                          options={"block_threads": 256, "lds_bytes": 45056, "exact_stats": 1})
     base, st0 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, r.top_k, options={"exact_stats": 1})
     exp, _ = _oracle(indptr, indices, seeds, r.coef(), r.rmax, r.top_k)
     _assert_parity(seeds, r.top_k, base, exp)
@@ -389,7 +389,7 @@ def test_random_digraphs_all_launch_shapes(case):
     exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
     # default shape (direct-indexed tables when the graph fits), both forced shapes, the hashed 512-thread form
     for opts in ({}, {"block_threads": 1024, "lds_bytes": 163840}, {"block_threads": 512, "lds_bytes": 81920},
-                 {"block_threads": 512, "lds_bytes": 81920, "direct_tables": 0}, {"block_threads": 256, "lds_bytes": 40960}):
+                 {"block_threads": 512, "lds_bytes": 81920, "direct_tables": 0}, {"block_threads": 256, "lds_bytes": 45056}):
         got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options=dict(opts, exact_stats=1))
         _assert_parity(seeds, K, got, exp)
         assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"], (opts, st, ost)
@@ -408,7 +408,7 @@ def test_bucketed_level_bucket_overflow_falls_back_to_counting():
     coef = make_coef("ppr", 4, 0.3)
     K = 64
     got, st = _run_gpu(indptr, indices, seeds, coef, 0.0, K,
-                       options={"block_threads": 256, "lds_bytes": 40960, "exact_stats": 1})
+                       options={"block_threads": 256, "lds_bytes": 45056, "exact_stats": 1})
     exp, ost = _oracle(indptr, indices, seeds, coef, 0.0, K)
     _assert_parity(seeds, K, got, exp)
     assert st["failed_rows"] == 0 and st["global_levels"] == 0
@@ -489,7 +489,7 @@ def test_lds_budget_too_small_for_topk_is_rejected():
     from grand_plus_amd import Graph, synth
     indptr, indices = synth.shape_csr("tiny")
     g = Graph(indptr, indices, 0)
-    g.set_option("block_threads", 256); g.set_option("lds_bytes", 40960)
+    g.set_option("block_threads", 256); g.set_option("lds_bytes", 45056)
     seeds = synth.seeds(len(indptr) - 1, 8)
     K = 1000
     row = np.zeros(8 * K, np.int32); col = np.zeros(8 * K, np.int32); val = np.zeros(8 * K)

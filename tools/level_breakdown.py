@@ -37,7 +37,9 @@ def main():
         print(f"   per row (us): prologue {dx[4] / rows / 100:.2f}  level0 {dx[5] / rows / 100:.2f}  level-loop outside expand/scan {dx[6] / rows / 100:.2f}  "
               f"table restore {dx[7] / rows / 100:.2f}  topk {st['diag_ticks_topk'] / rows / 100:.2f}", flush=True)
         print("   SCAN of wave 0 (cycles/row): compact (a,b) %.0f  records (c) %.0f  lookups+entries (d) %.0f  tail %.0f" % tuple(dx[8 + i] / rows for i in range(4)), flush=True)
-        print("   EXPAND stream of wave 0 (cycles/row): prepare %.0f  wait for columns %.0f  inserts %.0f  total %.0f;  per row: steps %.1f  batches %.1f  calls %.1f" % tuple(dx[112 + i] / rows for i in (0, 1, 2, 5, 3, 4, 6)), flush=True)
+        print("   EXPAND stream of wave 0 (cycles/row): prepare %.0f  wait for columns %.0f  inserts %.0f  total %.0f;  per row: steps %.1f  first-step chain (cycles) %.0f  calls %.1f" % tuple(dx[112 + i] / rows for i in (0, 1, 2, 5, 3, 4, 6)), flush=True)
+        print("   EXPAND of wave 0 (cycles/row): call -> first instruction of edge_stream %.0f, its end -> behind the barrier %.0f" % (dx[122] / rows, dx[123] / rows), flush=True)
+        print("   EXPAND calls: longest wave %.0f cycles/row, mean wave %.0f cycles/row (sum over waves / waves)" % (dx[120] / rows, dx[121] / rows / (st["block_threads"] / 64)), flush=True)
         names = ["agg_init", "agg_insert", "agg_scan", "sel_hist", "sel_pick", "sel_compact", "sel_collect", "final"]
         print("   topk sub-phases (us/row):", {n: round(st["diag_sub"][i] / rows / 100, 2) for i, n in enumerate(names)}, flush=True)
         if os.environ.get("GP_SITES"):

@@ -80,8 +80,14 @@ constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= 
 #define GP_FLAT_W 4
 #endif
 constexpr int    kFlatW      = GP_FLAT_W;       // EXPAND: 64-edge windows a wave keeps in flight (column loads issued together)
+// -DGP_DIAG: thread 0 stamps the phases with the 100 MHz wall clock (cheap).  Unless -DGP_DIAG_LIGHT is given as well, every
+// barrier additionally measures what each wave waits there and EXPAND / SCAN stamp their sub-phases with the shader clock --
+// detailed, but it inflates the row time by a third, so per-phase shares are best read from the light build.
+#if defined(GP_DIAG) && !defined(GP_DIAG_LIGHT)
+#define GP_DIAG_HEAVY 1
+#endif
 #ifdef GP_DIAG
-constexpr int    kCtlStruct  = 2048 + 64;    // (diagnostic build: + per-barrier-site wait counters)
+constexpr int    kCtlStruct  = 4096;    // (diagnostic build: + per-barrier-site wait counters)
 #else
 constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic LDS ...
 #endif
@@ -146,6 +152,8 @@ struct Ctl {
     u32 tk_wide;          // top-K: a candidate lies outside [2^-63, 2): the first digit needs the 4096-bin histogram
     u64 st_row[12];       // statistics of the row in flight: added to st[] when the row completes, dropped when it is handed to the retry launch
 #ifdef GP_DIAG
+    u64 lvl_acc[16][6];   // per level: expand ticks, scan ticks, edges, frontier nodes, push entries, table passes (flushed once per workgroup)
+    u64 row_acc[4];       // per row: prologue, level 0, level loop outside EXPAND/SCAN, table restore (ticks)
     u64 barw[16];         // per wave: shader cycles spent waiting at workgroup barriers
     u32 barn[16];         // per wave: barriers passed
     u64 exp_c0, exp_c2, exp_pre, exp_post;   // wave 0: cycles from before the EXPAND call to the first instruction of edge_stream / from its last to behind the barrier
@@ -200,7 +208,7 @@ enum Counter { kQueue = 0, kQueueRetry, kRetryRows,          // zeroed at every 
 // Phase stamps exist only in the diagnostic build (-DGP_DIAG): thread 0 reads the constant
 // 100 MHz clock at phase boundaries.  The product build compiles them to nothing.
 // Workgroup barrier.  The diagnostic build measures what the waves spend waiting at it (shader cycles).
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
 constexpr int kSyncBase = __COUNTER__;
 #define GP_SYNC() do { constexpr int site_ = (__COUNTER__ - kSyncBase - 1) & 63; const u64 tb_ = clock64(); __syncthreads(); if ((threadIdx.x & 63) == 0) { const u64 w_ = clock64() - tb_; ctl->barw[threadIdx.x >> 6] += w_; ++ctl->barn[threadIdx.x >> 6]; \
     __hip_atomic_fetch_add(&ctl->site_w[site_], w_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&ctl->site_n[site_], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } } while (0)
@@ -269,6 +277,14 @@ __device__ __forceinline__ KP kparams() {
 
 // ---------------------------------------------------------------- small helpers
 // Multiplicative (Fibonacci-style) hashes; slot_of() consumes the HIGH bits.
+#ifndef GP_CHEAP_HASH
+#define GP_CHEAP_HASH 0
+#endif
+#if GP_CHEAP_HASH
+// One multiply each (32-bit integer multiplies are quarter-rate instructions, and EXPAND hashes every edge twice)
+__device__ __forceinline__ u32 hash_a(u32 k) { return k * 0x9E3779B1u; }
+__device__ __forceinline__ u32 hash_b(u32 k) { const u32 h = k * 0x7FEB352Du; return h ^ (h << 13); }
+#else
 __device__ __forceinline__ u32 hash_a(u32 k) {            // residue / aggregation tables
     k *= 0x9E3779B1u; k ^= k >> 15; k *= 0x85EBCA77u;
     return k;
@@ -277,6 +293,7 @@ __device__ __forceinline__ u32 hash_b(u32 k) {            // partition choice (i
     k *= 0x7FEB352Du; k ^= k >> 16; k *= 0x846CA68Bu;
     return k;
 }
+#endif
 __device__ __forceinline__ u32 slot_of(u32 h, u32 cap) { return (u32)(((u64)h * cap) >> 32); }
 // Home slot in an LDS table of `cap` slots.  Homes lie in [0, cap - kProbeSpan): a probe sequence then
 // never leaves [0, cap), so the probing loops need no wrap-around (4 VALU per probe); 2 % of a full
@@ -461,6 +478,94 @@ __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 ca
     if (slot == 0xFFFFFFFFu) *flag = 1u;
     else __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
+}
+
+// Four inserts per lane with their probing chains INTERLEAVED (the four 64-edge windows of an EXPAND step).  One window's
+// chain is a sequence of dependent LDS round trips whose length is the LONGEST of its 64 lanes' probe sequences (4-7 probes
+// at the load factors of the peak levels), and a step ran four such chains one after the other: more than half of a wave's
+// EXPAND time.  Here every round issues the compare-and-swaps of all four windows back to back, waits once, and narrows each
+// window's mask of still-searching lanes (kept in an SGPR pair: EXEC is loaded from it around the window's instructions), so
+// a step costs max(chain lengths) round trips instead of their sum, at about the same instruction count (39 per round of
+// four vs 10 per probe).  act[w] = lanes that insert in window w.  Sets *flag when a lane exceeds the probe limit.
+#ifndef GP_INSERT4
+#define GP_INSERT4 0          // measured: MAG -5 %, Reddit -3 %, Pubmed -4 % (fewer dependent LDS round trips do not pay for the pressure: the function leaves the caller-saved registers)
+#endif
+__device__ __forceinline__ void insert4_lds(int* keys, double* vals, u32 cap, const int (&k)[4], const double (&v)[4],
+                                            const u64 (&act)[4], u32* flag)
+{
+    if ((act[0] | act[1] | act[2] | act[3]) == 0) return;                  // wave-uniform
+    u32 s0 = home_lds((u32)k[0], cap), s1 = home_lds((u32)k[1], cap), s2 = home_lds((u32)k[2], cap), s3 = home_lds((u32)k[3], cap);
+    u64 m0 = act[0], m1 = act[1], m2 = act[2], m3 = act[3];
+    u32 r0, r1, r2, r3; u64 sv, t; u32 st;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "1:\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "v_lshl_add_u32 %[r0], %[s0], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[r0], %[r0], %[emp], %[k0]\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "v_lshl_add_u32 %[r1], %[s1], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[r1], %[r1], %[emp], %[k1]\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "v_lshl_add_u32 %[r2], %[s2], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[r2], %[r2], %[emp], %[k2]\n\t"
+        "s_mov_b64 exec, %[m3]\n\t"
+        "v_lshl_add_u32 %[r3], %[s3], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[r3], %[r3], %[emp], %[k3]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "v_cmpx_ne_u32 vcc, %[r0], %[k0]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[r0]\n\t"
+        "v_add_u32 %[s0], %[st], %[s0]\n\t"
+        "s_mov_b64 %[m0], exec\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "v_cmpx_ne_u32 vcc, %[r1], %[k1]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[r1]\n\t"
+        "v_add_u32 %[s1], %[st], %[s1]\n\t"
+        "s_mov_b64 %[m1], exec\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "v_cmpx_ne_u32 vcc, %[r2], %[k2]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[r2]\n\t"
+        "v_add_u32 %[s2], %[st], %[s2]\n\t"
+        "s_mov_b64 %[m2], exec\n\t"
+        "s_mov_b64 exec, %[m3]\n\t"
+        "v_cmpx_ne_u32 vcc, %[r3], %[k3]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[r3]\n\t"
+        "v_add_u32 %[s3], %[st], %[s3]\n\t"
+        "s_mov_b64 %[m3], exec\n\t"
+        "s_or_b64 %[t], %[m0], %[m1]\n\t"
+        "s_or_b64 vcc, %[m2], %[m3]\n\t"
+        "s_or_b64 %[t], %[t], vcc\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_add_u32 %[st], %[st], 1\n\t"
+        "s_cmp_le_u32 %[st], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        // the lanes that found or claimed their slot add their share
+        "s_andn2_b64 exec, %[c0], %[m0]\n\t"
+        "v_lshl_add_u32 %[r0], %[s0], 3, %[vb]\n\t"
+        "ds_add_f64 %[r0], %[v0]\n\t"
+        "s_andn2_b64 exec, %[c1], %[m1]\n\t"
+        "v_lshl_add_u32 %[r1], %[s1], 3, %[vb]\n\t"
+        "ds_add_f64 %[r1], %[v1]\n\t"
+        "s_andn2_b64 exec, %[c2], %[m2]\n\t"
+        "v_lshl_add_u32 %[r2], %[s2], 3, %[vb]\n\t"
+        "ds_add_f64 %[r2], %[v2]\n\t"
+        "s_andn2_b64 exec, %[c3], %[m3]\n\t"
+        "v_lshl_add_u32 %[r3], %[s3], 3, %[vb]\n\t"
+        "ds_add_f64 %[r3], %[v3]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3),
+          [m0] "+&s"(m0), [m1] "+&s"(m1), [m2] "+&s"(m2), [m3] "+&s"(m3),     // (early clobber: never the registers of act[])
+          [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3),
+          [sv] "=&s"(sv), [t] "=&s"(t), [st] "=&s"(st)
+        : [k0] "v"(k[0]), [k1] "v"(k[1]), [k2] "v"(k[2]), [k3] "v"(k[3]),
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
+          [c0] "s"(act[0]), [c1] "s"(act[1]), [c2] "s"(act[2]), [c3] "s"(act[3]),
+          [emp] "v"(kEmpty), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
+    if ((m0 | m1 | m2 | m3) != 0 && (threadIdx.x & 63) == 0) *flag = 1u;    // a lane gave up at the probe limit (wave-uniform test)
 }
 
 // Direct-indexed table for graphs with N <= slots (Cora, Citeseer): the slot IS the node id, so an insert
@@ -677,7 +782,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
     const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
     const u32 wb = wave_id() * range;
     u32 tot = 0;
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
     u64 ss0 = clock64(), ss1 = 0, ss2 = 0, ss3 = 0;
 #endif
     for (u32 sub = wb; sub < wb + range && sub < cap; sub += 256u) {
@@ -706,7 +811,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         tot += c0 + c1 + c2 + c3;
     }
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
     ss1 = ss2 = ss3 = clock64();
 #endif
     if (tot != 0) {
@@ -748,7 +853,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
             }
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
         ss2 = ss3 = clock64();
 #endif
         // (d) the nodes that may push: V x 64 per step, their indptr loads in flight together
@@ -788,7 +893,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
             }
         }
     }
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
     if (tot != 0) ss3 = clock64();
 #endif
     // edge totals of the next level and the statistics: one LDS atomic per wave (64 same-address
@@ -801,7 +906,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
             if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
         }
     }
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
     if (tid == 0) {
         const u64 ss4 = clock64();
         ctl->scan_sub[0] += ss1 - ss0; ctl->scan_sub[1] += ss2 - ss1; ctl->scan_sub[2] += ss3 - ss2; ctl->scan_sub[3] += ss4 - ss3;
@@ -852,7 +957,7 @@ __device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* pus
     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave;
     const int* indices = p.indices;
     const u32 sentinel = (u32)p.nnz;
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
     if (threadIdx.x == 0) { const u64 c1_ = clock64(); ctl->exp_pre += c1_ - ctl->exp_c0; ctl->exp_c2 = c1_; }
 #endif
     const u32 units = (E + (1u << kUnitShift) - 1u) >> kUnitShift;
@@ -862,7 +967,7 @@ __device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* pus
     const u32 u_lo = (u32)(((u64)slot * units) / kWaves), u_hi = (u32)(((u64)(slot + 1) * units) / kWaves);
     if (u_lo >= u_hi || n_ent == 0) return;
     const bool small = n_ent <= 64u;                                           // (wave-uniform) the whole list in one wave
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
     u64 xs[7] = {0, 0, 0, 0, 0, 0, 1}; u64 x0 = clock64(), xa = x0, xb;
 #define GP_XS(i) do { xb = clock64(); xs[i] += xb - xa; xa = xb; } while (0)
 #define GP_XS_FLUSH() do { xs[5] = clock64() - x0; if (threadIdx.x == 0) { for (int i_ = 0; i_ < 7; ++i_) ctl->exp_sub[i_] += xs[i_]; ctl->exp_c2 = clock64(); } \
@@ -950,7 +1055,7 @@ __device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* pus
         int cc[4]; double cs[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; cs[w] = ns[w]; }
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
         if (cc[0] == 0x7FFFFFF0 && cc[1] == 0x7FFFFFF0 && cc[2] == 0x7FFFFFF0 && cc[3] == 0x7FFFFFF0) xs[6] += 1;      // (uses the loaded values: the wait is charged here)
         GP_XS(1); xs[3] += 1;
 #endif
@@ -976,6 +1081,16 @@ __device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double*
 {
     u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
     edge_stream<BLOCK>(p, ctl, push, bt, n_ent, E, dry, [&](const int (&v)[4], const double (&sh)[4]) {
+#if GP_INSERT4
+        if (IN_LDS && !DIRECT) {
+            u64 act[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                act[w] = __ballot(v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part));
+            insert4_lds(lkeys, lvals, cap, v, sh, act, flag);                                          // graph.h:98
+            return;
+        }
+#endif
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             if (v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part))
@@ -1673,7 +1788,8 @@ __device__ __forceinline__ void gfpush_rows()
     u64 gp_sub_t = 0; u64 gp_sub_acc[16];
     for (int i = 0; i < 16; ++i) gp_sub_acc[i] = 0;
     if (tid < 16) { ctl->barw[tid] = 0; ctl->barn[tid] = 0; }
-    if (tid < 4) ctl->scan_sub[tid] = 0;
+    if (tid < 4) { ctl->scan_sub[tid] = 0; ctl->row_acc[tid] = 0; }
+    if (tid < 96) ctl->lvl_acc[tid / 6][tid % 6] = 0;
     if (tid < 8) ctl->exp_sub[tid] = 0;
     if (tid == 0) { ctl->exp_max = 0; ctl->exp_sum_max = 0; ctl->exp_sum_all = 0; ctl->exp_pre = 0; ctl->exp_post = 0; ctl->exp_c0 = 0; ctl->exp_c2 = 0; }
     if (tid < 64) { ctl->site_w[tid] = 0; ctl->site_n[tid] = 0; }
@@ -1841,6 +1957,8 @@ __device__ __forceinline__ void gfpush_rows()
                         GP_STAMP(t0);
 #ifdef GP_DIAG
                         ++lv_passes;
+#endif
+#ifdef GP_DIAG_HEAVY
                         if (tid == 0) ctl->exp_c0 = clock64();
 #endif
                         if (BLOCK == 512 && direct) {
@@ -1854,7 +1972,7 @@ __device__ __forceinline__ void gfpush_rows()
                             phase_expand<BLOCK, 1>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
                         }
                         GP_SYNC();
-#ifdef GP_DIAG
+#ifdef GP_DIAG_HEAVY
                         if (tid == 0) { ctl->exp_sum_max += ctl->exp_max; ctl->exp_max = 0; ctl->exp_post += clock64() - ctl->exp_c2; }
 #endif
                         GP_STAMP(t1); GP_ACCUM(tk_expand, t0, t1); if (!in_lds) GP_ACCUM(tk_expand_hbm, t0, t1);
@@ -1891,14 +2009,10 @@ __device__ __forceinline__ void gfpush_rows()
             }
             if (tid == 0) stat_add(ctl, in_lds ? sLds : sGlb, 1);
 #ifdef GP_DIAG
-            if (tid == 0) {
-                u64* dx = p.counters + kDiagX0 + 16 + 6 * min(lvl, 15);
-                __hip_atomic_fetch_add(dx + 0, tk_expand - lv_e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dx + 1, tk_scan - lv_s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dx + 2, (u64)e_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dx + 3, (u64)(ctl->log_count - snap_log), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dx + 4, (u64)n_ent_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dx + 5, (u64)lv_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {            // (in LDS: a global atomic here would be awaited at the next phase call's entry)
+                u64* dx = ctl->lvl_acc[min(lvl, 15)];
+                dx[0] += tk_expand - lv_e0; dx[1] += tk_scan - lv_s0; dx[2] += (u64)e_cur;
+                dx[3] += (u64)(ctl->log_count - snap_log); dx[4] += (u64)n_ent_cur; dx[5] += (u64)lv_passes;
             }
 #endif
             {
@@ -1927,9 +2041,8 @@ __device__ __forceinline__ void gfpush_rows()
         GP_STAMP(t0);
 #ifdef GP_DIAG
         if (tid == 0) {       // [4] row prologue, [5] level 0, [6] level loop outside EXPAND/SCAN, [7] table restore after TOP-K (added below)
-            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 4], rs1 - rs0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 5], rs2 - rs1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 6], (t0 - rs2) - (tk_expand - lv_all_e0) - (tk_scan - lv_all_s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl->row_acc[0] += rs1 - rs0; ctl->row_acc[1] += rs2 - rs1;
+            ctl->row_acc[2] += (t0 - rs2) - (tk_expand - lv_all_e0) - (tk_scan - lv_all_s0);
         }
         if (!(p.diag_flags & 1))
 #endif
@@ -1942,7 +2055,7 @@ __device__ __forceinline__ void gfpush_rows()
         wipe_table<BLOCK>(lkeys, lvals, C);
 #ifdef GP_DIAG
         GP_STAMP(rs3);
-        if (tid == 0) __hip_atomic_fetch_add(&p.counters[kDiagX0 + 7], rs3 - t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) ctl->row_acc[3] += rs3 - t1;
 #endif
     }
 
@@ -1967,6 +2080,10 @@ __device__ __forceinline__ void gfpush_rows()
         __hip_atomic_fetch_add(&p.counters[kTicksExpandHbm], tk_expand_hbm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = 0; i < 16; ++i)
             __hip_atomic_fetch_add(&p.counters[kDiag0 + i], gp_sub_acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 4; ++i)
+            __hip_atomic_fetch_add(&p.counters[kDiagX0 + 4 + i], ctl->row_acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 96; ++i)
+            if (ctl->lvl_acc[i / 6][i % 6]) __hip_atomic_fetch_add(&p.counters[kDiagX0 + 16 + i], ctl->lvl_acc[i / 6][i % 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
 #ifdef GP_DIAG

@@ -27,7 +27,7 @@ EXPORTS = (
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
-    "gp_graph_create_multi", "gp_graph_num_gpus",
+    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan",
 )
 
 

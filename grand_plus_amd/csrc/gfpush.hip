@@ -91,6 +91,7 @@ struct gp_graph {
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
     double est_rmax = -1.0; int est_n_coef = 0;                            // the call parameters that estimate belongs to
+    bool est_recipe_changed = false; double cur_e_est = 0.0; int64_t last_call_rows = 0;
     // per-call state
     Workspace ws;
     u64* d_counters = nullptr; u64* h_counters = nullptr;      // pinned host mirror
@@ -106,7 +107,7 @@ struct gp_graph {
     bool multi = false; int n_parts = 0; int force_collective = 0; int gather_host = 0; int64_t min_rows_per_gpu = 2048;
     std::vector<gp_graph*> part; std::vector<int> devices;
     std::vector<ncclComm_t> comms; bool comms_ready = false;
-    std::vector<char*> m_slab, m_gather; std::vector<int*> m_seeds; size_t m_stride = 0; int64_t m_per = 0;
+    std::vector<char*> m_slab, m_gather; std::vector<int*> m_seeds; std::vector<size_t> m_cap_stride; std::vector<int64_t> m_cap_per;
     char* m_host = nullptr; size_t m_host_bytes = 0;
     gp_stats m_last{}; bool m_has_stats = false;
     // one packed slab [val f64 x slots | row i32 x slots | col i32 x slots | filled i32 x seeds] on the device and one pinned
@@ -202,10 +203,12 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
     }
     if (g->est_rmax != rmax || g->est_n_coef != n_coef) {            // a new recipe: forget the running estimate
         g->est_rmax = rmax; g->est_n_coef = n_coef; g->est_edges = 0.0; g->est_log = 0.0;
+        g->est_recipe_changed = true;                                // (the observed maxima on the device belong to the old recipe)
     }
     double e_est = g->est_level_edges > 0 ? (double)g->est_level_edges
                                           : std::max(g->est_edges, std::max(32768.0, bound / 4.0));
     e_est = std::min(e_est, bound);
+    g->cur_e_est = e_est;
     double log_est = e_est >= bound ? 0.0 : std::max(g->est_log, 4.0 * e_est);
     Slabs est = slab_sizes(g, n_coef, e_est, log_est);
     while ((double)est.per_wg() * n_wg > 0.5 * (double)budget && e_est > 4096.0) {     // shrink the slabs, not the launch
@@ -324,6 +327,28 @@ int load_rccl() {
 // (the layout of grand_plus_amd/sharded.py:packed_stride, so both multi-GPU drivers move the same slab)
 size_t packed_stride(int64_t per, int K) { return ((size_t)16 * per * K + (size_t)4 * per + 15) / 16 * 16; }
 
+// How one call is cut over the GPUs of a multi-GPU handle (pure host arithmetic: gp_internal_multi_plan exposes it to the
+// CPU tests, because the >= 2-GPU branch cannot run on a one-GPU box).
+//   G   GPUs that compute (1 when the call is too small to shard and no collective is forced)
+//   Gc  GPUs that take part in the gather (the whole communicator for the RCCL path, else G)
+//   per rows every participant contributes to the gather = ceil(S / G); GPU d computes rows [d per, min((d+1) per, S))
+//   single: the call is handed to part[0] as it is (no slab, no gather)
+struct MultiPlan { int G = 1, Gc = 1; int64_t per = 0; size_t stride = 0; bool single = true; };
+MultiPlan plan_multi(int64_t n_seeds, int K, int n_parts, int64_t min_rows_per_gpu, bool force_collective, bool gather_host) {
+    MultiPlan m;
+    m.G = n_parts;
+    if (n_seeds < min_rows_per_gpu * (int64_t)m.G && !force_collective) m.G = 1;       // small calls stay on one GPU
+    m.single = m.G == 1 && !force_collective;
+    m.per = (n_seeds + m.G - 1) / m.G;
+    m.stride = packed_stride(m.per, K);
+    m.Gc = gather_host ? m.G : n_parts;                    // the communicator spans every GPU of the handle
+    return m;
+}
+void plan_block(const MultiPlan& m, int d, int64_t n_seeds, int64_t* lo, int64_t* n) {
+    *lo = std::min<int64_t>((int64_t)d * m.per, n_seeds);
+    *n = d < m.G ? std::min<int64_t>(*lo + m.per, n_seeds) - *lo : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -367,6 +392,16 @@ int gp_internal_diag_counters(gp_graph* g, int64_t* out, int n) {
 
 void gp_internal_set_error(int status, const char* where, const char* detail) {
     (void)fail(status, "%s: %s", where ? where : "", detail ? detail : "");
+}
+
+int gp_internal_multi_plan(int64_t n_seeds, int K, int n_parts, int64_t min_rows_per_gpu, int force_collective, int gather_host,
+                           int64_t* out, int n_out)
+{
+    if (!out || n_parts < 1 || K < 1 || n_seeds < 0 || n_out < 5 + 2 * n_parts) return fail(GP_ERR_INVALID_ARG, "gp_internal_multi_plan: bad argument");
+    const MultiPlan m = plan_multi(n_seeds, K, n_parts, min_rows_per_gpu, force_collective != 0, gather_host != 0);
+    out[0] = m.G; out[1] = m.Gc; out[2] = m.per; out[3] = (int64_t)m.stride; out[4] = m.single ? 1 : 0;
+    for (int d = 0; d < n_parts; ++d) plan_block(m, d, n_seeds, &out[5 + 2 * d], &out[6 + 2 * d]);
+    return GP_OK;
 }
 
 int gp_device_count(void) {
@@ -526,6 +561,21 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     // workspace and counters are per graph: launches on one stream are ordered by the stream,
     // a launch on a DIFFERENT stream first waits for the previous one
     if (g->launched && g->last_stream != s) HIP_TRY(hipStreamSynchronize(g->last_stream));
+    // Grow the slab estimate from what the previous call observed, whether or not the caller ever asks for statistics
+    // (callers of this entry point that never call gp_get_stats kept the first estimate forever, and every row
+    // above it was serialised onto the few workgroups of the retry launch): once that call has completed, its counters are
+    // in the pinned mirror.  More than 2 % of its rows retried => at least double the per-level estimate.
+    if (g->launched && g->est_level_edges == 0 && g->est_rmax == rmax && g->est_n_coef == n_coef) {
+        const hipError_t qs = hipStreamQuery(g->last_stream);
+        if (qs == hipSuccess) {
+            g->est_edges = std::max(g->est_edges, 1.5 * (double)g->h_counters[kMaxLevelEdges]);
+            g->est_log = std::max(g->est_log, 1.5 * (double)g->h_counters[kMaxLogRecords]);
+            if (g->last_call_rows > 0 && (double)g->h_counters[kRetryRows] > 0.02 * (double)g->last_call_rows)
+                g->est_edges = std::max(g->est_edges, 2.0 * g->cur_e_est);
+        } else if (qs != hipErrorNotReady) {
+            (void)hipGetLastError();
+        }
+    }
 
     // Geometry.  Two 512-thread workgroups per CU (80 KB of LDS each) or one 1024-thread workgroup owning all
     // 160 KB.  All waves of a workgroup move through a row's phases together, so they wait for memory together
@@ -598,7 +648,10 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         g->reset_pending = false; g->rows_total = 0;
     } else {
         HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * (kRetryRows + 1), s));   // the two queue heads and the retry count
+        if (g->est_recipe_changed)                                                          // maxima of another recipe must not size this one's slabs
+            HIP_TRY(hipMemsetAsync(g->d_counters + kMaxLevelEdges, 0, sizeof(u64) * 2, s));
     }
+    g->est_recipe_changed = false;
     if (w.dirty) {
         hipLaunchKernelGGL(init_tables_kernel, dim3(4096), dim3(256), 0, s, w.est.resg, (u64)w.est.n_wg * w.est.resg_cap);
         if (w.big.n_wg > 0)
@@ -659,7 +712,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     }
     HIP_TRY(hipEventRecord(g->ev1, s));
     HIP_TRY(hipMemcpyAsync(g->h_counters, g->d_counters, sizeof(u64) * kNumCounters, hipMemcpyDeviceToHost, s));
-    g->launched = true; g->last_stream = s;
+    g->launched = true; g->last_stream = s; g->last_call_rows = n_seeds;
     std::memset(&g->last, 0, sizeof g->last);
     g->rows_total += n_seeds;
     g->last.rows = g->rows_total;
@@ -703,8 +756,8 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     s.retried_rows = (int64_t)g->h_counters[kRetriedTotal];
     s.max_level_edges = (int64_t)g->h_counters[kMaxLevelEdges];
     s.max_log_records = (int64_t)g->h_counters[kMaxLogRecords];
-    // grow the estimate the next call's slabs are sized from: 1.5 x the largest level / log seen so far, and at
-    // least double it when more than 2 % of the rows had to take the retry launch
+    // grow the estimate the next call's slabs are sized from: 1.5 x the largest level / log seen so far
+    // (gp_gfpush_device does the same, and the doubling after a call with > 2 % retried rows, when it starts)
     if (g->est_level_edges == 0) {
         g->est_edges = std::max(g->est_edges, 1.5 * (double)s.max_level_edges);
         g->est_log = std::max(g->est_log, 1.5 * (double)s.max_log_records);
@@ -884,46 +937,48 @@ void scatter_filled(const char* slab, int64_t per, int K, int64_t row0, int64_t 
 int gfpush_multi(gp_graph* g, const int32_t* seeds, int64_t n_seeds, const double* coef, int n_coef, double rmax, int K,
                  int32_t* row_idx, int32_t* col_idx, double* value)
 {
-    int G = g->n_parts;
-    if (n_seeds < g->min_rows_per_gpu * (int64_t)G && !g->force_collective) G = 1;     // small calls stay on one GPU
-    if (G == 1 && !g->force_collective) {
+    const MultiPlan plan = plan_multi(n_seeds, K, g->n_parts, g->min_rows_per_gpu, g->force_collective != 0, g->gather_host != 0);
+    const int G = plan.G, Gc = plan.Gc;
+    if (plan.single) {
         int rc = gp_gfpush(g->part[0], seeds, n_seeds, coef, n_coef, rmax, K, row_idx, col_idx, value);
         gp_stats st; const int rc2 = gp_get_stats(g->part[0], &st);
         g->m_last = st; g->m_has_stats = true;
         return rc ? rc : rc2;
     }
-    for (int d = 1; d < G; ++d)
-        if (!g->part[d]) { int rc = replicate_part(g, d); if (rc) return rc; }
     const bool collective = !g->gather_host;
+    for (int d = 1; d < Gc; ++d)
+        if (!g->part[d]) { int rc = replicate_part(g, d); if (rc) return rc; }
     if (collective && !g->comms_ready) {
         int rc = load_rccl();
         if (rc) return rc;
         RCCL_TRY(g_rccl.CommInitAll(g->comms.data(), g->n_parts, g->devices.data()));
         g->comms_ready = true;
     }
-    const int64_t per = (n_seeds + G - 1) / G;
-    const size_t stride = packed_stride(per, K);
-    const int Gc = collective ? g->n_parts : G;            // the communicator spans every GPU of the handle
-    if (stride > g->m_stride || per > g->m_per) {          // m_stride / m_per: CAPACITY of the per-GPU buffers (bytes / seeds)
-        for (int d = 0; d < g->n_parts; ++d) {
-            if (!g->part[d]) { if (d < Gc) { int rc = replicate_part(g, d); if (rc) return rc; } else continue; }
-            HIP_TRY(hipSetDevice(g->devices[d]));
-            if (g->m_slab[d]) (void)hipFree(g->m_slab[d]);
-            if (g->m_gather[d]) (void)hipFree(g->m_gather[d]);
-            if (g->m_seeds[d]) (void)hipFree(g->m_seeds[d]);
-            g->m_slab[d] = g->m_gather[d] = nullptr; g->m_seeds[d] = nullptr;
-            HIP_TRY(hipMalloc(&g->m_slab[d], stride));
-            HIP_TRY(hipMalloc(&g->m_gather[d], stride * (size_t)g->n_parts));
-            HIP_TRY(hipMalloc(&g->m_seeds[d], sizeof(int) * (size_t)std::max<int64_t>(std::max(per, g->m_per), 1)));
-        }
-        g->m_per = std::max(per, g->m_per); g->m_stride = stride;
+    const int64_t per = plan.per;
+    const size_t stride = plan.stride;
+    // Per-GPU buffers, tracked per part (a part created after an earlier call's allocation has none yet -- ADVICE r2):
+    // its slab, the gather target (every GPU receives every slab) and its seed block.
+    if (g->m_cap_stride.size() != (size_t)g->n_parts) { g->m_cap_stride.assign(g->n_parts, 0); g->m_cap_per.assign(g->n_parts, 0); }
+    for (int d = 0; d < Gc; ++d) {
+        if (g->m_slab[d] && g->m_cap_stride[d] >= stride && g->m_cap_per[d] >= per) continue;
+        HIP_TRY(hipSetDevice(g->devices[d]));
+        if (g->m_slab[d]) (void)hipFree(g->m_slab[d]);
+        if (g->m_gather[d]) (void)hipFree(g->m_gather[d]);
+        if (g->m_seeds[d]) (void)hipFree(g->m_seeds[d]);
+        g->m_slab[d] = g->m_gather[d] = nullptr; g->m_seeds[d] = nullptr; g->m_cap_stride[d] = 0; g->m_cap_per[d] = 0;
+        const size_t cap_s = std::max(stride, g->m_cap_stride[d]);
+        const int64_t cap_p = std::max<int64_t>(std::max(per, g->m_cap_per[d]), 1);
+        HIP_TRY(hipMalloc(&g->m_slab[d], cap_s));
+        HIP_TRY(hipMalloc(&g->m_gather[d], cap_s * (size_t)g->n_parts));
+        HIP_TRY(hipMalloc(&g->m_seeds[d], sizeof(int) * (size_t)cap_p));
+        g->m_cap_stride[d] = cap_s; g->m_cap_per[d] = cap_p;
+    }
+    if (stride * (size_t)g->n_parts > g->m_host_bytes) {
         if (g->m_host) (void)hipHostFree(g->m_host);
         g->m_host = nullptr; g->m_host_bytes = 0;
         HIP_TRY(hipSetDevice(g->devices[0]));
         HIP_TRY(hipHostMalloc(&g->m_host, stride * (size_t)g->n_parts));
         g->m_host_bytes = stride * (size_t)g->n_parts;
-    } else if (collective) {
-        for (int d = 0; d < Gc; ++d) if (!g->part[d]) { int rc = replicate_part(g, d); if (rc) return rc; }
     }
     const size_t cur_stride = stride;                      // this call's layout (the buffers may be larger)
     const int64_t cur_per = per;
@@ -932,11 +987,10 @@ int gfpush_multi(gp_graph* g, const int32_t* seeds, int64_t n_seeds, const doubl
     std::vector<int> rcs(Gc, GP_OK);
     std::vector<std::string> errs(Gc);
     std::vector<std::thread> pool;
-    const int64_t blk = (n_seeds + G - 1) / G;             // rows per computing GPU
     auto work = [&](int d) {
         gp_graph* q = g->part[d];
-        const int64_t lo = std::min<int64_t>((int64_t)d * blk, n_seeds), hi = d < G ? std::min<int64_t>(lo + blk, n_seeds) : lo;
-        const int64_t n = hi - lo;
+        int64_t lo, n;
+        plan_block(plan, d, n_seeds, &lo, &n);
         auto run = [&]() -> int {
             HIP_TRY(hipSetDevice(q->device));
             char* slab = g->m_slab[d];
@@ -974,7 +1028,9 @@ int gfpush_multi(gp_graph* g, const int32_t* seeds, int64_t n_seeds, const doubl
         gp_graph* q = g->part[d];
         HIP_TRY(hipSetDevice(q->device));
         HIP_TRY(hipStreamSynchronize(q->stream));
-        if (!q->launched || d >= G) continue;
+        int64_t lo_d, n_d;
+        plan_block(plan, d, n_seeds, &lo_d, &n_d);
+        if (!q->launched || n_d == 0) continue;            // (a part that got no rows this call still holds an earlier call's counters)
         gp_stats st; const int rc = gp_get_stats(q, &st);
         if (rc && !status) status = rc;
         sum.rows += st.rows; sum.pushes += st.pushes; sum.edges += st.edges; sum.filled += st.filled; sum.support += st.support;
@@ -989,8 +1045,9 @@ int gfpush_multi(gp_graph* g, const int32_t* seeds, int64_t n_seeds, const doubl
     g->m_last = sum; g->m_has_stats = true;
     if (status) return status;
     for (int d = 0; d < G; ++d) {
-        const int64_t lo = std::min<int64_t>((int64_t)d * blk, n_seeds), hi = std::min<int64_t>(lo + blk, n_seeds);
-        scatter_filled(g->m_host + (size_t)d * cur_stride, cur_per, K, lo, hi - lo, row_idx, col_idx, value);
+        int64_t lo, n;
+        plan_block(plan, d, n_seeds, &lo, &n);
+        scatter_filled(g->m_host + (size_t)d * cur_stride, cur_per, K, lo, n, row_idx, col_idx, value);
     }
     return GP_OK;
 }

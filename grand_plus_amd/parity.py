@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 TAU_VAL = 1e-9    # measured worst case of the HIP path vs the fp64 oracle is ~1e-13
-TAU_TIE = 1e-9
+TAU_TIE = 1e-12   # a tie is two totals that differ by summation-order ulps, nothing looser
 
 
 @dataclass
@@ -57,8 +57,13 @@ def rows_as_dicts(seeds, K, row_idx, col_idx, value, fill=None):
 
 
 def compare_rows(seeds, K, got, exp, fill=None, tau_val=TAU_VAL, tau_tie=TAU_TIE,
-                 max_messages=10) -> ParityReport:
-    """Compare two (row_idx, col_idx, value) triples under the tie-aware rule."""
+                 max_messages=10, next_value=None) -> ParityReport:
+    """Compare two (row_idx, col_idx, value) triples under the tie-aware rule.
+
+    ``next_value`` (optional, one per row): the (K+1)-th largest value of the EXPECTED implementation's full reserve map
+    (oracle.pyoracle.gfpush(..., want_next=True)).  When given, a row whose index set differs is accepted as a tie row
+    only if that value really ties with the K-th expected value -- the tie is then proven in the oracle's own reserve,
+    not inferred from the produced values."""
     rep = ParityReport()
     g_rows = rows_as_dicts(seeds, K, *got, fill=fill)
     e_rows = rows_as_dicts(seeds, K, *exp, fill=fill)
@@ -92,6 +97,10 @@ def compare_rows(seeds, K, got, exp, fill=None, tau_val=TAU_VAL, tau_tie=TAU_TIE
                     if c not in ed and abs(v - kth) > tau_tie * kth:
                         why = f"extra col {c} value {v!r} not tied with kth {kth!r}"
                         break
+            if why is None and not same and next_value is not None:
+                nv = float(next_value[it])
+                if abs(nv - kth) > tau_tie * kth:
+                    why = f"index sets differ but the expected reserve holds no tie at K: kth {kth!r}, (K+1)-th {nv!r}"
             if why is None:
                 if same:
                     rep.exact_index_rows += 1

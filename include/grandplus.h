@@ -225,6 +225,13 @@ int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indic
  * (k = 0 expand ticks, 1 scan ticks, 2 edges, 3 frontier nodes, 4 push-list entries, 5 table passes); n <= 128 */
 int gp_internal_diag_counters(gp_graph* g, int64_t* out, int n);
 
+/* internal (host arithmetic only, no GPU needed): how gp_gfpush cuts a call of n_seeds rows over the n_parts GPUs of a
+ * multi-GPU handle.  out[0] = GPUs that compute, [1] = GPUs in the gather, [2] = rows per GPU = ceil(S / G),
+ * [3] = bytes per packed slab, [4] = 1 when the call is handed to GPU 0 as it is; then (first row, rows) per GPU.
+ * n_out >= 5 + 2 * n_parts.  The CPU tests drive the >= 2-GPU partitioning through this seam. */
+int gp_internal_multi_plan(int64_t n_seeds, int K, int n_parts, int64_t min_rows_per_gpu, int force_collective, int gather_host,
+                           int64_t* out, int n_out);
+
 /* internal: lets the second translation unit report through gp_last_error (not for callers) */
 void gp_internal_set_error(int status, const char* where, const char* detail);
 

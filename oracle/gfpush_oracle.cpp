@@ -41,11 +41,14 @@ extern "C" {
 //   stats[5] = max over rows,levels of frontier size         (residue map size)
 //   stats[6] = number of dangling returns                    (graph.h:91 taken)
 //   stats[7] = sum over rows,levels of frontier size
-int gfpush_oracle(const int32_t* indptr, int64_t n_nodes, const int32_t* indices,
-                  const int32_t* seeds, int64_t n_seeds,
-                  const double* coef, int n_coef, double rmax, int K,
-                  int32_t* row_idx, int32_t* col_idx, double* value,
-                  int n_threads, int64_t* stats)
+// next_value (optional, n_seeds doubles): the (K+1)-th largest reserve value of every row (0 when the reserve map holds
+// at most K nodes).  The parity comparator uses it to PROVE that a row whose index set differs from the checked
+// implementation's holds a tie at the K-th position in the full reserve map (graph.h:115 picks arbitrarily there).
+int gfpush_oracle_ex(const int32_t* indptr, int64_t n_nodes, const int32_t* indices,
+                     const int32_t* seeds, int64_t n_seeds,
+                     const double* coef, int n_coef, double rmax, int K,
+                     int32_t* row_idx, int32_t* col_idx, double* value,
+                     int n_threads, int64_t* stats, double* next_value)
 {
     if (!indptr || !indices || !seeds || !coef || !row_idx || !col_idx || !value) return -1;
     if (n_coef < 1 || K < 1 || n_nodes < 0 || n_seeds < 0) return -2;
@@ -101,6 +104,11 @@ int gfpush_oracle(const int32_t* indptr, int64_t n_nodes, const int32_t* indices
             return a.second > b.second || (a.second == b.second && a.first < b.first);
         };
         std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), better);  // graph.h:115
+        if (next_value) {
+            double nv = 0.0;
+            for (size_t i = k; i < cand.size(); ++i) nv = std::max(nv, cand[i].second);
+            next_value[it] = nv;
+        }
         for (size_t i = 0; i < k; ++i) {                             // graph.h:117-126
             if (cand[i].second > 0.0) {                              // graph.h:121
                 const int64_t slot = it * (int64_t)K + (int64_t)i;
@@ -116,6 +124,16 @@ int gfpush_oracle(const int32_t* indptr, int64_t n_nodes, const int32_t* indices
         stats[4] = mS; stats[5] = mFr; stats[6] = tD; stats[7] = tFr;
     }
     return 0;
+}
+
+int gfpush_oracle(const int32_t* indptr, int64_t n_nodes, const int32_t* indices,
+                  const int32_t* seeds, int64_t n_seeds,
+                  const double* coef, int n_coef, double rmax, int K,
+                  int32_t* row_idx, int32_t* col_idx, double* value,
+                  int n_threads, int64_t* stats)
+{
+    return gfpush_oracle_ex(indptr, n_nodes, indices, seeds, n_seeds, coef, n_coef, rmax, K, row_idx, col_idx, value,
+                            n_threads, stats, nullptr);
 }
 
 int gfpush_oracle_max_threads(void) { return omp_get_max_threads(); }

@@ -30,14 +30,33 @@ def _oracle(indptr, indices, seeds, coef, rmax, K, fill=(0, 0, 0.0)):
     row = np.full(S * K, fill[0], np.int32)
     col = np.full(S * K, fill[1], np.int32)
     val = np.full(S * K, fill[2], np.float64)
-    r, c, v, st = pyoracle.gfpush(indptr, indices, seeds, coef, rmax, K, row, col, val)
-    return (r, c, v), st
+    r, c, v, st = pyoracle.gfpush(indptr, indices, seeds, coef, rmax, K, row, col, val, want_next=True)
+    rows = _OracleRows((r, c, v))
+    rows.next_value = st["next_value"]           # picked up by _assert_parity: ties must be ties in the oracle's reserve
+    return rows, st
 
 
-def _assert_parity(seeds, K, got, exp, fill=None):
+class _OracleRows(tuple):
+    """(row_idx, col_idx, value) of the oracle + the (K+1)-th reserve value of every row."""
+    next_value = None
+
+
+def _assert_parity(seeds, K, got, exp, fill=None, next_value=None, max_tie_frac=None, label=""):
+    """Tie-aware parity (grand_plus_amd/parity.py).  next_value = the oracle's (K+1)-th reserve value per row: a row whose
+    index set differs must then hold a PROVEN tie at the K-th position of the oracle's full reserve map."""
     from grand_plus_amd.parity import compare_rows
-    rep = compare_rows(np.asarray(seeds), K, got, exp, fill=fill)
+    if next_value is None:
+        next_value = getattr(exp, "next_value", None)
+        if next_value is not None and len(next_value) != len(seeds):
+            next_value = None                    # (a caller compared a sub-range)
+    rep = compare_rows(np.asarray(seeds), K, tuple(got), tuple(exp), fill=fill, next_value=next_value)
     assert rep.ok, "\n".join(rep.messages)
+    assert rep.exact_index_rows + rep.tie_rows == rep.rows
+    if label:
+        print(f"[parity] {label}: {rep.rows} rows = {rep.exact_index_rows} exact index sets + {rep.tie_rows} tie rows "
+              f"({rep.tie_rows / max(rep.rows, 1):.3f}), max rel err {rep.max_rel_err:.2e}")
+    if max_tie_frac is not None:
+        assert rep.tie_rows <= max_tie_frac * rep.rows, f"{rep.tie_rows} tie rows of {rep.rows}"
     return rep
 
 
@@ -79,7 +98,7 @@ def test_synthetic_small(mode, order, alpha, rmax, K, force_global):
     _assert_parity(seeds, K, got2, got)          # pruned aggregation selects the same rows
     assert st2["pushes"] == st["pushes"] and st2["filled"] == st["filled"] and st2["support"] <= st["support"]
     exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
-    _assert_parity(seeds, K, got, exp)
+    _assert_parity(seeds, K, got, exp, next_value=ost["next_value"])
     assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"]
     assert st["filled"] == ost["filled"] and st["support"] == ost["support_sum"]
     assert st["frontier"] == ost["frontier_sum"]
@@ -104,7 +123,11 @@ def test_reference_golden_through_dropin_module(name, mode):
     row = np.zeros(n_use * K, np.int32); col = np.zeros(n_use * K, np.int32); val = np.zeros(n_use * K, np.float64)
     assert g.gfpush_omp(seeds, row, col, val, z[f"{mode}_coef"], rmax, K) is None
     exp = (z[f"{mode}_row"], z[f"{mode}_col"], z[f"{mode}_val"])
-    rep = _assert_parity(seeds, K, (row, col, val), exp)
+    # the (K+1)-th reserve value of every row from the restatement (proven equal to the reference in tests/test_oracle.py):
+    # an index set may differ from the reference's only where its reserve map really ties at the K-th position;
+    # SURVEY.md 8c probed 4-30 % such rows on the citation graphs
+    _, ost = _oracle(z["indptr"], z["indices"], seeds.astype(np.int32), z[f"{mode}_coef"], rmax, K)
+    rep = _assert_parity(seeds, K, (row, col, val), exp, next_value=ost["next_value"], max_tie_frac=0.30, label=f"{name}/{mode}")
     assert rep.max_rel_err < 1e-12            # fp64 path: differences are summation-order ulps only
     # topk_adj of the caller (model.py:270-272) is then identical up to ties
     import scipy.sparse as sp

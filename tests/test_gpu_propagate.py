@@ -91,3 +91,21 @@ def test_fp32_storage_drift_after_20_steps_stays_below_1e_6():
         drift = np.abs(got - ref).max() / np.abs(ref).max()
         assert drift <= 1e-6, f"{name}: drift {drift:.2e}"
         assert np.abs(got - ref.astype(np.float32)).max() <= 4e-7 * np.abs(ref).max() + 1e-30
+
+
+def test_multi_gpu_handle_propagates_on_its_first_gpu():
+    """A multi-GPU handle owns no device memory itself (the CSR lives in its first part): propagate_features on it must
+    give the single-GPU result instead of faulting on null pointers."""
+    import scipy.sparse as sp
+    import torch
+    from grand_plus_amd import Graph
+    from oracle.predict_ref import propagate_ref
+    z = np.load(os.path.join(GOLD, "cora.npz"))
+    indptr, indices = z["indptr"], z["indices"]
+    n = len(indptr) - 1
+    X = np.random.default_rng(3).standard_normal((n, 32)).astype(np.float32)
+    ref = propagate_ref(sp.csr_matrix((np.ones(len(indices)), indices, indptr), shape=(n, n)), X, "ppr", 4, 0.2)
+    g = Graph(indptr, indices, 0, n_gpus=0)
+    got = g.propagate_features(torch.from_numpy(X).cuda(), "ppr", 4, 0.2).cpu().numpy()
+    assert np.all(np.abs(got - ref) <= 2e-6 * np.abs(ref) + 1e-6 * np.abs(ref).max())
+    g.close()

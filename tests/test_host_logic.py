@@ -168,3 +168,49 @@ def test_bench_kernel_hash_is_stable_and_traffic_is_tied_to_it():
     import bench
     sha = bench.kernel_source_sha16()
     assert re.fullmatch(r"[0-9a-f]{16}", sha) and sha == bench.kernel_source_sha16()
+
+
+def test_multi_gpu_partition_arithmetic_through_the_host_seam():
+    """gp_gfpush on a multi-GPU handle: how a call is cut over the GPUs (graph.h:73-74 -- rows are independent, so any
+    contiguous cut is valid; what must hold is that the cut COVERS every row exactly once and matches the packed-slab
+    layout both multi-GPU drivers move).  The >= 2-GPU branch cannot execute on a one-GPU box, so its arithmetic is
+    driven through gp_internal_multi_plan (pure host code, the function gfpush_multi itself calls)."""
+    from grand_plus_amd import _native
+    from grand_plus_amd.sharded import packed_stride, shard_range
+    L = _native.lib()
+    L.gp_internal_multi_plan.restype = ctypes.c_int
+    L.gp_internal_multi_plan.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+
+    def plan(S, K, parts, min_rows=2048, force=0, host=0):
+        out = (ctypes.c_int64 * (5 + 2 * parts))()
+        assert L.gp_internal_multi_plan(S, K, parts, min_rows, force, host, out, len(out)) == 0
+        v = list(out)
+        return dict(G=v[0], Gc=v[1], per=v[2], stride=v[3], single=bool(v[4]), blocks=[(v[5 + 2 * d], v[6 + 2 * d]) for d in range(parts)])
+
+    for parts in (1, 2, 3, 4, 8):
+        for S in (0, 1, 7, 2047, 2048 * parts - 1, 2048 * parts, 65536, 65537, 262144 + 5):
+            for K in (1, 16, 32, 64):
+                for force, host in ((0, 0), (1, 0), (0, 1), (1, 1)):
+                    p = plan(S, K, parts, force=force, host=host)
+                    big = S >= 2048 * parts
+                    assert p["G"] == (parts if (big or force) else 1)
+                    assert p["single"] == (p["G"] == 1 and not force)
+                    assert p["Gc"] == (p["G"] if host else parts)               # the communicator spans the whole handle
+                    assert p["per"] == -(-S // p["G"])                          # ceil(S / G): the ragged last block is padded
+                    assert p["stride"] == packed_stride(p["per"], K) and p["stride"] % 16 == 0
+                    # blocks: contiguous, disjoint, cover [0, S) exactly once; non-computing GPUs get nothing
+                    pos = 0
+                    for d, (lo, n) in enumerate(p["blocks"]):
+                        if d < p["G"]:
+                            assert (lo, lo + n) == shard_range(S, p["G"], d)[:2]   # the same cut as the one-process-per-GPU driver
+                            assert lo == min(pos, S) and 0 <= n <= p["per"]
+                            pos = lo + n
+                        else:
+                            assert n == 0
+                    assert pos == S
+    # a smaller second call on the same handle re-uses buffers: the plan depends on the call alone
+    assert plan(4096, 32, 2) == plan(4096, 32, 2)
+    assert plan(100, 32, 4, min_rows=10)["G"] == 4 and plan(39, 32, 4, min_rows=10)["G"] == 1
+    out = (ctypes.c_int64 * 4)()
+    assert L.gp_internal_multi_plan(10, 4, 2, 1, 0, 0, out, 4) != 0             # output array too small: refused

@@ -343,6 +343,8 @@ def run_rank(args) -> int:
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if source.startswith("synth:") else "fixture graph (tests/golden), seeds cycled",
+            "value_clock": "inputs resident in HBM when the timed region starts (task contract); the metric's own clock -- host buffers in -> "
+                           "host buffers out through gp_gfpush, PCIe included -- is host_api.rows_per_s in this same line",
             "rccl_ranks": rccl_ranks, "kernel_ms_per_rank": per_rank_ms,
             "config": {"workload": desc, "recipe": f"{recipe.prop_mode} order {recipe.order} alpha {recipe.alpha} rmax {recipe.rmax} K {K}",
                        "seeds_per_gpu": per, "rows_per_step": S_step, "n_nodes": n_nodes, "nnz": int(len(indices)),
@@ -374,13 +376,18 @@ def run_rank(args) -> int:
         # same command, tools/collect_pmc.sh) and committed under profiles/ together with the hash of the kernel
         # sources it was measured on; a bench run cannot profile itself, and a profile of OTHER sources is not reported.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_mag_pmc_summary.json")))
+            pname = "r03_mag_pmc_summary.json"
+            prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
             if args.workload == prof.get("workload") and per == prof.get("seeds_per_gpu") and world == 1:
                 if prof.get("kernel_sha16") == sha:
-                    line["roofline"]["traffic"] = int(prof["derived"]["hbm_read_bytes_raw"] + prof["derived"]["hbm_write_bytes"])
-                    line["roofline"]["traffic_source"] = "profiles/r02_mag_pmc_summary.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, raw counters, same kernel sources; see the note there about the gfx950 read counter)"
+                    dd = prof["derived"]
+                    line["roofline"]["traffic"] = int(dd["hbm_read_bytes_corrected"] + dd["hbm_write_bytes"])
+                    line["roofline"]["traffic_over_algorithmic"] = round(line["roofline"]["traffic"] / bytes_per_launch, 2)
+                    line["roofline"]["traffic_source"] = (f"profiles/{pname}: rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command on the same "
+                                                          "kernel sources; reads = TCC_EA0_RDREQ x 128 B (one request per 128-byte L2 line on gfx950, "
+                                                          "calibrated by tools/fetch_calib.sh -> profiles/r03_fetch_calib.json; FETCH_SIZE tallies 64), writes = WRITE_SIZE")
                 else:
-                    line["roofline"]["traffic_source"] = f"none: profiles/r02_mag_pmc_summary.json was measured on kernel sources {prof.get('kernel_sha16')}, this run is {sha}"
+                    line["roofline"]["traffic_source"] = f"none: profiles/{pname} was measured on kernel sources {prof.get('kernel_sha16')}, this run is {sha}"
         except (OSError, KeyError, ValueError):
             pass
         if stats.get("diag_ticks_total"):
@@ -408,7 +415,12 @@ def run_rank(args) -> int:
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(indptr, indices, all_seeds[args.warmup * S_step:], recipe, args.cpu_budget_s)
             line["cpu_baseline"] = cb
-            line["detail"]["gpu_over_cpu"] = round(value / cb["value"], 1)
+            # like clocks: the CPU number is host buffers in -> host buffers out, so it is compared with the host-API rate
+            # (gp_gfpush, PCIe included); the device-resident `value` over the same CPU number is kept beside it
+            if "host_api" in line:
+                line["detail"]["gpu_over_cpu"] = round(line["host_api"]["rows_per_s"] / cb["value"], 1)
+                line["detail"]["gpu_over_cpu_clock"] = "host buffers in -> host buffers out on both sides (host_api.rows_per_s / cpu_baseline.value)"
+            line["detail"]["gpu_device_resident_over_cpu"] = round(value / cb["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -73,6 +73,7 @@ __device__ __forceinline__ double uni(double x) {
 }
 
 constexpr int    kEmpty      = -1;
+constexpr int    kCoefLds    = 40;      // coefficients kept in the control block (more: read from global memory)
 constexpr u32    kUnitShift  = 6;       // EXPAND hands out a level's edges in units of 64 (one window; a step = up to 4 units)
 constexpr int    kTopkBins   = 4096;    // 12-bit radix digits
 constexpr int    kBucketCap  = 256;     // finish the select by ranking once <= this many remain
@@ -103,6 +104,10 @@ constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed 
 #endif
 constexpr u32    kMinCap     = GP_MIN_CAP;    // smallest table capacity used for a level
 constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts with before it uses the HBM table instead
+#ifndef GP_LOAD_NUM
+#define GP_LOAD_NUM 3u          // a level is expanded in one pass while its edge count is <= GP_LOAD_NUM / GP_LOAD_DEN of the table's slots
+#define GP_LOAD_DEN 4u
+#endif
 #ifndef GP_BUCKET_MIN
 #define GP_BUCKET_MIN 3
 #endif
@@ -151,6 +156,8 @@ struct Ctl {
     u64 st[12];           // statistics of this workgroup (Stat), flushed to p.counters once at the end
     u32 tk_wide;          // top-K: a candidate lies outside [2^-63, 2): the first digit needs the 4096-bin histogram
     u64 st_row[12];       // statistics of the row in flight: added to st[] when the row completes, dropped when it is handed to the retry launch
+    double coef[kCoefLds]; // the first coefficients of the recipe: every level starts by reading its own (a global load there is a
+                          // dependent round trip on the row's critical path, 11 of them per MAG row)
 #ifdef GP_DIAG
     u64 lvl_acc[16][6];   // per level: expand ticks, scan ticks, edges, frontier nodes, push entries, table passes (flushed once per workgroup)
     u64 row_acc[4];       // per row: prologue, level 0, level loop outside EXPAND/SCAN, table restore (ticks)
@@ -1579,15 +1586,21 @@ __device__ __forceinline__ WgView wg_view(KP p, u32 lds0) {
     w.bt2     = p.bt + wg * 2 * p.bt_cap;
     return w;
 }
-#ifdef GP_DIAG
 #define GP_PHASE_NOINLINE static __attribute__((noinline))
+// -DGP_INLINE_HOT=1 (A/B): EXPAND and the dense SCAN inlined into the level loop again (what a call costs: the callee's
+// entry waits for ALL outstanding memory operations of the wave, its prologue re-derives the workgroup's pointers)
+#ifndef GP_INLINE_HOT
+#define GP_INLINE_HOT 0
+#endif
+#if GP_INLINE_HOT
+#define GP_PHASE_HOT static __forceinline__
 #else
-#define GP_PHASE_NOINLINE static __attribute__((noinline))
+#define GP_PHASE_HOT GP_PHASE_NOINLINE
 #endif
 
 // EXPAND of one level (or one hash partition of it).  MODE 0: LDS hash table, 1: HBM table, 2: direct-indexed LDS table.
 template <int BLOCK, int MODE>
-__device__ GP_PHASE_NOINLINE void phase_expand(u32 lds0, u32 cap, u32 cur, u32 n_ent, u32 E, u32 part, u32 np,
+__device__ GP_PHASE_HOT void phase_expand(u32 lds0, u32 cap, u32 cur, u32 n_ent, u32 E, u32 part, u32 np,
                                                u32 has_dang, double dang, int seed_key, u32 dry)
 {
     KP p = kparams();
@@ -1610,7 +1623,7 @@ __device__ GP_PHASE_NOINLINE void phase_expand(u32 lds0, u32 cap, u32 cur, u32 n
 // SCAN of one level's (or partition's) LDS table; what it produces for the next level goes to ctl->lc[nx_sel] and to the
 // push buffer nxt_sel.
 template <int BLOCK>
-__device__ GP_PHASE_NOINLINE void phase_scan_dense(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, double c, u32 do_push)
+__device__ GP_PHASE_HOT void phase_scan_dense(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, double c, u32 do_push)
 {
     KP p = kparams();
     lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); c = uni(c); do_push = uni(do_push);
@@ -1778,6 +1791,7 @@ __device__ __forceinline__ void gfpush_rows()
 
     wipe_table<BLOCK>(lkeys, lvals, C);
     if (tid < (int)(sizeof(ctl->st) / sizeof(ctl->st[0]))) { ctl->st[tid] = 0; ctl->st_row[tid] = 0; }      // visible after the first row's barriers
+    if (tid < kCoefLds && tid < p.n_coef) ctl->coef[tid] = p.coef[tid];
     const long long n_rows = p.n_rows_dev ? (long long)*p.n_rows_dev : p.n_seeds;    // rows in this launch's queue
     u32 max_e = 0, max_log = 0;                                                      // observed maxima of this workgroup
     u64 tk_scan = 0, tk_expand = 0, tk_topk = 0, tk_total = 0, t0 = 0, t1 = 0, t2 = 0, tk_begin = 0;
@@ -1852,7 +1866,7 @@ __device__ __forceinline__ void gfpush_rows()
         //      record, its push test and its push-list entry are written directly.  This removes one
         //      EXPAND/SCAN round trip (two barriers, a table walk and a dependent indptr load) per row.
         {
-            const double c0 = uni(p.coef[0]);
+            const double c0 = uni(ctl->coef[0]);
             PushEntry* push_nxt0 = push2 + (size_t)1 * p.push_cap;
             if (tid == 0) {
                 if (p.log_cap > 0) { log_key[0] = seed_key; log_val[0] = c0; }                         // graph.h:90 / :109
@@ -1891,7 +1905,7 @@ __device__ __forceinline__ void gfpush_rows()
         const u64 lv_all_e0 = tk_expand, lv_all_s0 = tk_scan;
 #endif
         for (int lvl = 1; lvl <= L; ++lvl) {
-            const double c = uni(p.coef[lvl]);
+            const double c = uni(lvl < kCoefLds ? ctl->coef[lvl] : p.coef[lvl]);
             const bool do_push = lvl < L;                                     // graph.h:83 vs :104
             // distinct targets of this level <= min(edges (+ the seed), N)
             const u64 need = min((u64)e_cur + (has_dang_cur ? 1 : 0), (u64)p.n_nodes);
@@ -1905,14 +1919,14 @@ __device__ __forceinline__ void gfpush_rows()
             if (direct) {
                 cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
             } else if (in_lds) {
-                if (need * 4 <= (u64)C * 3) {
+                if (need * GP_LOAD_DEN <= (u64)C * GP_LOAD_NUM) {
                     cap = min(C, max(kMinCap, ((u32)GP_CAP_MULT * (u32)need + 3u) & ~3u));
                 } else if (need > (u64)kMaxParts * C) {
                     in_lds = false;                      // more than kMaxParts partitions: the HBM table
                 } else {
                     // target load of a partition: 0.75 of the table counted in EDGES (distinct targets are ~15 % fewer); a partition
                     // that overflows anyway is split in place.  0.55 -> 0.75 saved half a pass on the peak levels of the 80 KB shape (+2 %).
-                    parts = ((u32)need * 4u + C * 3u - 1u) / (C * 3u);       // need <= 64 C < 2^21: 32-bit arithmetic
+                    parts = ((u32)need * GP_LOAD_DEN + C * GP_LOAD_NUM - 1u) / (C * GP_LOAD_NUM);       // need <= 64 C < 2^21: 32-bit arithmetic
                     cap = C;
                     if (parts > kMaxParts) in_lds = false;
                 }

@@ -27,9 +27,15 @@ g = per.get
 d = {}
 if g("TCC_EA0_RDREQ_sum"): d["hbm_read_bytes_raw"] = g("TCC_EA0_RDREQ_sum") * 64
 elif g("FETCH_SIZE"): d["hbm_read_bytes_raw"] = g("FETCH_SIZE") * 1024
+# Calibrated (tools/fetch_calib.sh -> profiles/r03_fetch_calib.json): on gfx950 every TCC_EA0_RDREQ is the fill of one
+# 128-byte L2 line -- streams of 16 B/lane and of a 4-B + 8-B SoA pair read 128.0 bytes per request, random runs of 4 / 14 /
+# 64 words and single-word gathers produce exactly one request per 128-byte line they touch -- and FETCH_SIZE tallies it
+# at 64 B (TCC_BUBBLE, its 128-byte term, stays 0).  So the bytes that cross the L2 -> fabric boundary are 2 x raw.
+if "hbm_read_bytes_raw" in d: d["hbm_read_bytes_corrected"] = 2.0 * d["hbm_read_bytes_raw"]
 if g("WRITE_SIZE"): d["hbm_write_bytes"] = g("WRITE_SIZE") * 1024
-for k in ("hbm_read_bytes_raw", "hbm_write_bytes"):
-    if k in d: d[k.replace("bytes", "kb_per_row").replace("_raw", "")] = d[k] / 1024 / a.rows
+for k in ("hbm_read_bytes_corrected", "hbm_write_bytes"):
+    if k in d: d[k.replace("bytes", "kb_per_row").replace("_corrected", "")] = d[k] / 1024 / a.rows
+if "hbm_read_bytes_corrected" in d and "hbm_write_bytes" in d: d["hbm_traffic_bytes"] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
 if g("TCC_HIT_sum") and g("TCC_MISS_sum"): d["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
 for c, n in (("SQ_INSTS_VALU", "valu_per_row"), ("SQ_INSTS_SALU", "salu_per_row"), ("SQ_INSTS_LDS", "lds_insts_per_row"),
              ("SQ_INSTS_VMEM_RD", "vmem_rd_per_row"), ("SQ_INSTS_VMEM_WR", "vmem_wr_per_row")):
@@ -46,6 +52,6 @@ for _f in ("grand_plus_amd/csrc/gfpush_kernels.hpp", "grand_plus_amd/csrc/gfpush
 json.dump({"workload": a.workload, "seeds_per_gpu": a.rows, "kernel_sha16": _h.hexdigest()[:16],
            "command": "tools/collect_pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows (one pass per group; mean of the 5 timed main launches)",
            "kernel": "gp::gfpush_kernel", "per_launch": per, "derived": d,
-           "note": "FETCH_SIZE = TCC_EA0_RDREQ x 64 B / 1024. MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly 1/2 of a 16-B/lane coalesced stream; this kernel issues mostly 4-8 B/lane gathers (uncalibrated), so the true read volume lies between 1x and 2x of hbm_read_bytes_raw. Infinity-Cache hits are included. SQ_* cycle counters are in quad-cycles; SQ_BUSY_CYCLES is summed over the 32 shader engines."},
+           "note": "hbm_read_bytes_raw = TCC_EA0_RDREQ x 64 B (= FETCH_SIZE); hbm_read_bytes_corrected = TCC_EA0_RDREQ x 128 B: tools/fetch_calib.sh (profiles/r03_fetch_calib.json) shows one request per 128-byte L2 line for every access shape of this kernel (16-B/lane and SoA streams, runs of 4 / 14 / 64 words, single-word gathers). WRITE_SIZE is taken as it reads (exact for 16-B/lane streaming stores per MI355X_MICROARCH.md). Infinity-Cache hits are included in both. SQ_* cycle counters are in quad-cycles; SQ_BUSY_CYCLES is summed over the 32 shader engines."},
           open(a.out, "w"), indent=1)
 print(json.dumps(d, indent=1))

@@ -108,6 +108,9 @@ constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts w
 #define GP_LOAD_NUM 3u          // a level is expanded in one pass while its edge count is <= GP_LOAD_NUM / GP_LOAD_DEN of the table's slots
 #define GP_LOAD_DEN 4u
 #endif
+#ifndef GP_EVEN_WALK
+#define GP_EVEN_WALK 0          // capacities that give every wave of SCAN the same number of 256-slot steps: MAG -1.3 %, Reddit -1.4 %, Pubmed -1.2 % (the smaller table costs more than the even walk saves)
+#endif
 #ifndef GP_BUCKET_MIN
 #define GP_BUCKET_MIN 3
 #endif
@@ -1919,6 +1922,23 @@ __device__ __forceinline__ void gfpush_rows()
             if (direct) {
                 cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
             } else if (in_lds) {
+#if GP_EVEN_WALK
+                // SCAN hands every wave a range of whole 256-slot steps: a capacity that is a multiple of (waves x 256) gives every
+                // wave the SAME number of steps (6 378 slots over 12 waves were 3+3+3+3+3+3+3+3+1+0+0+0 steps; 6 144 are 2 each)
+                constexpr u32 gran = (BLOCK / 64) * 256u;
+                const u32 Ce = C >= 2u * gran ? (C / gran) * gran : C;           // the largest even-walk capacity
+                const u32 want = (u32)GP_CAP_MULT * (u32)min(need, (u64)C);
+                if (need * GP_LOAD_DEN <= (u64)Ce * GP_LOAD_NUM) {
+                    cap = want <= kMinCap ? kMinCap : min(Ce, ((want + gran - 1u) / gran) * gran);
+                    if (Ce == C) cap = min(C, max(kMinCap, (want + 3u) & ~3u));
+                } else if (need > (u64)kMaxParts * Ce) {
+                    in_lds = false;                      // more than kMaxParts partitions: the HBM table
+                } else {
+                    parts = ((u32)need * GP_LOAD_DEN + Ce * GP_LOAD_NUM - 1u) / (Ce * GP_LOAD_NUM);     // need <= 64 C < 2^21: 32-bit arithmetic
+                    cap = Ce;
+                    if (parts > kMaxParts) in_lds = false;
+                }
+#else
                 if (need * GP_LOAD_DEN <= (u64)C * GP_LOAD_NUM) {
                     cap = min(C, max(kMinCap, ((u32)GP_CAP_MULT * (u32)need + 3u) & ~3u));
                 } else if (need > (u64)kMaxParts * C) {
@@ -1930,6 +1950,7 @@ __device__ __forceinline__ void gfpush_rows()
                     cap = C;
                     if (parts > kMaxParts) in_lds = false;
                 }
+#endif
             }
             const u32 snap_log = uni(ctl->log_count);          // first log record of this level
 #ifdef GP_DIAG

@@ -127,7 +127,10 @@ def test_reference_golden_through_dropin_module(name, mode):
     # an index set may differ from the reference's only where its reserve map really ties at the K-th position;
     # SURVEY.md 8c probed 4-30 % such rows on the citation graphs
     _, ost = _oracle(z["indptr"], z["indices"], seeds.astype(np.int32), z[f"{mode}_coef"], rmax, K)
-    rep = _assert_parity(seeds, K, (row, col, val), exp, next_value=ost["next_value"], max_tie_frac=0.30, label=f"{name}/{mode}")
+    # measured: ppr / avg 3-14 % tie rows; `single` (the order-step matrix alone: values are products of 1/deg, so EXACT
+    # rational ties are the rule) 11-51 % -- every one of them proven by the oracle's (K+1)-th value
+    rep = _assert_parity(seeds, K, (row, col, val), exp, next_value=ost["next_value"],
+                         max_tie_frac=0.60 if mode == "single" else 0.30, label=f"{name}/{mode}")
     assert rep.max_rel_err < 1e-12            # fp64 path: differences are summation-order ulps only
     # topk_adj of the caller (model.py:270-272) is then identical up to ties
     import scipy.sparse as sp

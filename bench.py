@@ -204,6 +204,7 @@ def parse_args():
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--force-global", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="gp_set_option on the graph (A/B runs), e.g. --opt seedrow=0")
     ap.add_argument("--diag-flags", type=int, default=0, help="GRANDPLUS_DIAG=1 builds only: bit 0 skips TOP-K (instruction attribution)")
     return ap.parse_args()
 
@@ -262,6 +263,9 @@ def run_rank(args) -> int:
         graph.set_option("force_global", 1)
     if args.diag_flags:
         graph.set_option("diag_flags", args.diag_flags)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        graph.set_option(k, int(v))
 
     per = args.seeds_per_gpu
     S_step = per * world

@@ -84,10 +84,11 @@ struct gp_graph {
     int* d_indptr = nullptr; int* d_indices = nullptr;
     int deg_shift = 31; uint32_t node_mask = 0x7FFFFFFFu, deg_sat = 0;   // packed column ids (see pack_degree_kernel)
     bool packed = false; int max_degree_bits = 31;                        // packing happens at the first gfpush call
+    bool rows_distinct = false;                                           // every CSR row holds strictly increasing column ids
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
-    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1;
+    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1;
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
     double est_rmax = -1.0; int est_n_coef = 0;                            // the call parameters that estimate belongs to
@@ -431,6 +432,13 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
     uint32_t bad = 0;
     for (int64_t j = 0; j < nnz; ++j) bad |= (uint32_t)((uint32_t)indices[j] >= lim);
     if (bad) return fail(GP_ERR_INVALID_CSR, "a column id is outside [0, %lld)", (long long)n_nodes);
+    // Rows with strictly increasing column ids (what scipy's canonical CSR and the reference's loaders produce, model.py:243
+    // `adj + I` -> tocsr) let level 1 of every row skip its hash table: the seed's neighbours are then distinct by construction.
+    // A graph with repeated columns inside a row is legal (graph.h:96-99 adds the share once per stored entry) and simply does
+    // not get the shortcut.
+    uint32_t unsorted = 0;
+    for (int64_t i = 0; i < n_nodes; ++i)
+        for (int64_t j = (int64_t)indptr[i] + 1; j < indptr[i + 1]; ++j) unsorted |= (uint32_t)(indices[j] <= indices[j - 1]);
 
     const int ndev = gp_device_count();
     if (ndev <= 0) return fail(GP_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
@@ -441,7 +449,7 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
 
     gp_graph* g = new (std::nothrow) gp_graph();
     if (!g) return fail(GP_ERR_NOMEM, "host allocation failed");
-    g->device = device; g->n_nodes = n_nodes; g->nnz = nnz;
+    g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->rows_distinct = unsorted == 0;
     g->num_cus = prop.multiProcessorCount;
     int rc = GP_OK;
     auto cleanup = [&](int status) { gp_graph_destroy(g); return status; };
@@ -534,6 +542,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         g->exact_stats = value ? 1 : 0;
     } else if (k == "direct_tables") {
         g->direct_tables = value ? 1 : 0;        // 0 = always hash (testing / A-B of the direct-indexed small-graph tables)
+    } else if (k == "seedrow") {
+        g->seedrow = value ? 1 : 0;              // 0 = level 1 through EXPAND and a table like every other level (testing / A-B)
     } else if (k == "diag_flags") {
         g->diag_flags = (int)value;              // honoured by the -DGP_DIAG build only (bit 0: skip TOP-K)
     } else if (k == "max_degree_bits") {
@@ -683,7 +693,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.force_global = g->force_global;
     kp.prune = g->exact_stats ? 0 : 1;
     kp.diag_flags = g->diag_flags;
-    kp.pad_ll = 0;
+    kp.rows_distinct = g->rows_distinct && g->seedrow ? 1u : 0u;
     // direct-indexed level tables: the whole graph fits the table of the 512-thread kernel (Cora, Citeseer)
     kp.direct = (block_threads == 512 && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
@@ -893,10 +903,10 @@ int replicate_part(gp_graph* g, int d) {
     struct Guard { gp_graph* q; ~Guard() { if (q) gp_graph_destroy(q); } } guard{q};
     q->device = dev; q->n_nodes = src->n_nodes; q->nnz = src->nnz; q->num_cus = prop.multiProcessorCount;
     q->deg_shift = src->deg_shift; q->node_mask = src->node_mask; q->deg_sat = src->deg_sat;
-    q->packed = true; q->max_degree_bits = src->max_degree_bits;
+    q->packed = true; q->max_degree_bits = src->max_degree_bits; q->rows_distinct = src->rows_distinct;
     q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
     q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
-    q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges;
+    q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges; q->seedrow = src->seedrow;
     const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));

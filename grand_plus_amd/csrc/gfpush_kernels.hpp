@@ -266,7 +266,7 @@ struct KParams {
     u32 lds_slots;
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
-    u32 pad_ll;
+    u32 rows_distinct;                    // 1: every CSR row holds strictly increasing column ids (checked at gp_graph_create): level 1 needs no table
     int direct;                           // 1: every level's table is indexed by node id (N <= lds_slots; 512-thread kernel only)
     // Two launches per call.  The first gives every workgroup a slab sized from an ESTIMATE of a row's needs; a row that
     // outgrows it is not failed but appended to retry_list.  The second launch (a few workgroups, slabs sized from the
@@ -766,6 +766,9 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
     }
 }
 
+// Slots every wave may stage seed-row nodes in (scan_level_dense<BLOCK, true>): an equal, 4-aligned share of the table.
+template <int BLOCK> __device__ __forceinline__ u32 seedrow_slice(u32 C) { return (C / (u32)(BLOCK / 64)) & ~3u; }
+
 // ---------------------------------------------------------------- SCAN, LDS tables: compact, then process
 // The table of a level is at most ~25-50 % full, and the per-node work (log record, push test,
 // degree lookup, push-list entry) is ~10x the work of looking at a slot.  Walking the table with
@@ -775,10 +778,15 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
 // of the very slots just drained -- they are free, and LDS operations of one wave execute in
 // order -- and (c) the nodes are then processed 64 at a time with every lane busy.
 // Requires C % 4 == 0 and the invariant that slots in [cap, C) are empty.
-template <int BLOCK>
+// SEEDROW (level 1 of a row whose seed pushed, graphs whose CSR rows hold distinct columns): the level's frontier IS the
+// seed's neighbour list, every node with residue 1/deg(seed) (graph.h:96-99 applied to the one entry of level 0) -- no
+// table, no EXPAND, no barrier: every wave copies its share of the row (seed_start .. + seed_deg) into its slot range as
+// the compacted (key, residue) pairs that stages (a)+(b) would have produced, and continues with (c).
+template <int BLOCK, bool SEEDROW = false>
 __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, int* lkeys, double* lvals,
                                                  u32 cap, u32 C, int* log_key, double* log_val,
-                                                 PushEntry* push, u32* bt_g, double c, bool do_push)
+                                                 PushEntry* push, u32* bt_g, double c, bool do_push,
+                                                 u32 seed_start = 0, u32 seed_deg = 0, double seed_share = 0.0)
 {
     typedef int    i4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -789,13 +797,19 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
     // their indptr loads (and, vmcnt being shared, for the stores before them), so a level costs a
     // wave ceil(nodes / (64 V)) such waits -- not one or two per 256 slots as when (a)-(c) alternated.
     constexpr u32 kWaves = BLOCK / 64;
-    const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
+    const u32 range = SEEDROW ? seedrow_slice<BLOCK>(C) : ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
     const u32 wb = wave_id() * range;
     u32 tot = 0;
 #ifdef GP_DIAG_HEAVY
     u64 ss0 = clock64(), ss1 = 0, ss2 = 0, ss3 = 0;
 #endif
-    for (u32 sub = wb; sub < wb + range && sub < cap; sub += 256u) {
+    if (SEEDROW) {
+        const u32 lo = (u32)(((u64)wave_id() * seed_deg) / kWaves), hi = (u32)(((u64)(wave_id() + 1u) * seed_deg) / kWaves);
+        tot = hi - lo;                                              // <= range (the caller checked seed_deg <= kWaves * range)
+        for (u32 j = (u32)lane; j < tot; j += 64u) { lkeys[wb + j] = p.indices[seed_start + lo + j]; lvals[wb + j] = seed_share; }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    }
+    for (u32 sub = wb; !SEEDROW && sub < wb + range && sub < cap; sub += 256u) {
         // (a) drain 4 adjacent slots per lane
         const u32 s0 = sub + 4u * (u32)lane;
         i4 kk = {kEmpty, kEmpty, kEmpty, kEmpty};
@@ -1635,6 +1649,16 @@ __device__ GP_PHASE_HOT void phase_scan_dense(u32 lds0, u32 cap, u32 nx_sel, u32
                             w.push2 + (size_t)nxt_sel * p.push_cap, w.bt2 + (size_t)nxt_sel * p.bt_cap, c, do_push != 0);
 }
 template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_scan_seedrow(u32 lds0, u32 seed_start, u32 seed_deg, double share, double c, u32 do_push)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); seed_start = uni(seed_start); seed_deg = uni(seed_deg); share = uni(share); c = uni(c); do_push = uni(do_push);
+    const WgView w = wg_view(p, lds0);
+    // level 1: produces the push list of level 2 = buffer 0, counters lc[1]
+    scan_level_dense<BLOCK, true>(p, w.ctl, &w.ctl->lc[1], w.lkeys, w.lvals, w.C, w.C, w.log_key, w.log_val,
+                                  w.push2, w.bt2, c, do_push != 0, seed_start, seed_deg, share);
+}
+template <int BLOCK>
 __device__ GP_PHASE_NOINLINE void phase_scan_hbm(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, double c, u32 do_push)
 {
     KP p = kparams();
@@ -1864,6 +1888,7 @@ __device__ __forceinline__ void gfpush_rows()
         double dang_cur = 0.0;
         bool has_dang_cur = false;
         int cur = 0;
+        bool seedrow = false; double seed_share = 0.0;       // level 1 straight from the seed's CSR row (scan_level_dense<.., true>)
 
         // ---- level 0 without a table: the frontier is { seed : 1.0 } (graph.h:81), so its reserve
         //      record, its push test and its push-list entry are written directly.  This removes one
@@ -1887,6 +1912,12 @@ __device__ __forceinline__ void gfpush_rows()
                     if (tid == 0) { stat_add(ctl, sPush, 1); stat_add(ctl, sEdges, seed_deg); }
                     if (share != 0.0) {
                         e_cur = seed_deg; n_ent_cur = 1;
+                        seed_share = share;
+                        seedrow = p.rows_distinct && !p.force_global && !(BLOCK == 512 && p.direct) &&
+                                  seed_deg <= (u32)(BLOCK / 64) * seedrow_slice<BLOCK>(C);
+                        if (seedrow) {                       // level 1 needs neither the entry nor a table; its SCAN starts right behind this
+                            if (tid == 0) { LevelCtr* n1 = &ctl->lc[1]; n1->dangling = 0.0; n1->n_dangling = 0; n1->alloc = 0ull; }   // block's barrier
+                        } else
                         if (tid == 0) {
                             if (p.push_cap > 0) { PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push_nxt0[0] = pe; }
                             else ctl->fail = 1;
@@ -1894,7 +1925,8 @@ __device__ __forceinline__ void gfpush_rows()
                         // the one entry contains every 64-edge boundary of the level (a hub seed: many)
                         const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
                         u32* bt_g = w.bt2 + (size_t)1 * p.bt_cap;
-                        if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
+                        if (seedrow) { }
+                        else if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
                         else
                             for (u32 m = (u32)tid; m < units; m += BLOCK) bt_g[m] = 0u;
                     }
@@ -1960,7 +1992,8 @@ __device__ __forceinline__ void gfpush_rows()
             // read (previous level), this one was last read two levels ago: thread 0 may clear it
             // now, and SCAN only starts after the end-of-EXPAND barrier.  No barrier needed here.
             LevelCtr* nx = &ctl->lc[lvl & 1];
-            if (tid == 0) {
+            const bool lvl_seedrow = lvl == 1 && seedrow;      // (its counters were cleared in front of level 0's barrier)
+            if (tid == 0 && !lvl_seedrow) {
                 nx->dangling = 0.0; nx->n_dangling = 0; nx->alloc = 0ull;
             }
             if (!in_lds) {
@@ -1993,6 +2026,12 @@ __device__ __forceinline__ void gfpush_rows()
 #ifdef GP_DIAG
                         ++lv_passes;
 #endif
+                        if (lvl_seedrow) {
+                            phase_scan_seedrow<BLOCK>(lds0, s_start, seed_deg, seed_share, c, do_push ? 1u : 0u);
+                            GP_SYNC();
+                            GP_STAMP(t2); GP_ACCUM(tk_scan, t0, t2);
+                            break;
+                        }
 #ifdef GP_DIAG_HEAVY
                         if (tid == 0) ctl->exp_c0 = clock64();
 #endif

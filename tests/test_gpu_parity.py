@@ -558,3 +558,31 @@ def test_multi_gpu_handle_one_call_uses_every_gpu():
         g.close()
     exp, _ = _oracle(indptr, indices, seeds, r.coef(), r.rmax, K, fill=(-1, -1, -1.0))
     _assert_parity(seeds, K, single, exp, fill=(-1, -1, -1.0))
+
+
+def test_level_one_from_the_seed_row_equals_the_table_path():
+    """Level 1 of a row is the seed's neighbour list (graph.h:96-99 applied to level 0's one entry).  On CSRs with strictly
+    increasing columns per row the kernel takes it straight from the CSR row (option "seedrow", default on); rows, exact
+    counters and the oracle must agree with the table path.  A CSR with a REPEATED column inside a row (legal: the
+    reference adds the share once per stored entry) must not take the shortcut and still match the oracle."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import make_coef
+    indptr, indices = synth.shape_csr("small")
+    seeds = synth.seeds(len(indptr) - 1, 768)
+    for mode, order, rmax, K in (("ppr", 6, 1e-5, 16), ("avg", 2, 1e-6, 32), ("ppr", 1, 1e-5, 8)):
+        coef = make_coef(mode, order, 0.2)
+        on, st_on = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"exact_stats": 1})
+        off, st_off = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"exact_stats": 1, "seedrow": 0})
+        exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
+        _assert_parity(seeds, K, on, exp)
+        _assert_parity(seeds, K, off, exp)
+        for k in ("pushes", "edges", "filled", "support", "frontier"):
+            assert st_on[k] == st_off[k], k
+        assert st_on["pushes"] == ost["pushes"] and st_on["frontier"] == ost["frontier_sum"]
+    # duplicate columns: node 0 lists node 1 twice -> level 1 holds node 1 ONCE with residue 2/3
+    ip = np.array([0, 3, 5, 7, 9], np.int32)
+    ix = np.array([0, 1, 1, 0, 1, 2, 3, 2, 3], np.int32)
+    coef = make_coef("ppr", 4, 0.2)
+    got, _ = _run_gpu(ip, ix, [0, 1, 2, 3], coef, 0.0, 4)
+    exp, _ = _oracle(ip, ix, [0, 1, 2, 3], coef, 0.0, 4)
+    _assert_parity([0, 1, 2, 3], 4, got, exp)

@@ -9,6 +9,6 @@ ROWS=${ROWS:-16384}; STEPS=${STEPS:-3}
 for w in $W; do
   r=$ROWS; [ $w = amazon2m ] && r=4096
   for rep in 1 2; do for lib in $LIBS; do
-    GRANDPLUS_LIB=$lib python bench.py --workload $w --seeds-per-gpu $r --steps $STEPS --warmup 1 --no-cpu-baseline $BENCH_EXTRA 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$w $lib', round(d['value']), d['roofline']['kernel_ms_avg'])"
+    GRANDPLUS_LIB=$lib python bench.py --workload $w --seeds-per-gpu $r --steps $STEPS --warmup 2 --no-cpu-baseline $BENCH_EXTRA 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$w $lib', round(d['value']), d['roofline']['kernel_ms_avg'])"
   done; done
 done

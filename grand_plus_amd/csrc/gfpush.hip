@@ -92,7 +92,7 @@ struct gp_graph {
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
     double est_rmax = -1.0; int est_n_coef = 0;                            // the call parameters that estimate belongs to
-    bool est_recipe_changed = false; double cur_e_est = 0.0; int64_t last_call_rows = 0;
+    bool est_recipe_changed = false; double cur_e_est = 0.0, cur_log_est = 0.0; int64_t last_call_rows = 0;
     // per-call state
     Workspace ws;
     u64* d_counters = nullptr; u64* h_counters = nullptr;      // pinned host mirror
@@ -209,7 +209,6 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
     double e_est = g->est_level_edges > 0 ? (double)g->est_level_edges
                                           : std::max(g->est_edges, std::max(32768.0, bound / 4.0));
     e_est = std::min(e_est, bound);
-    g->cur_e_est = e_est;
     double log_est = e_est >= bound ? 0.0 : std::max(g->est_log, 4.0 * e_est);
     Slabs est = slab_sizes(g, n_coef, e_est, log_est);
     while ((double)est.per_wg() * n_wg > 0.5 * (double)budget && e_est > 4096.0) {     // shrink the slabs, not the launch
@@ -217,6 +216,7 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
         est = slab_sizes(g, n_coef, e_est, log_est);
     }
     if ((double)est.per_wg() * n_wg > 0.5 * (double)budget) n_wg = (int)std::max<size_t>(1, budget / 2 / est.per_wg());
+    g->cur_e_est = e_est; g->cur_log_est = log_est;
     est.n_wg = n_wg;
     Slabs big;                                                       // needed only if the estimate is below the bound
     if (e_est < bound || log_est > 0.0) {
@@ -578,8 +578,11 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     if (g->launched && g->est_level_edges == 0 && g->est_rmax == rmax && g->est_n_coef == n_coef) {
         const hipError_t qs = hipStreamQuery(g->last_stream);
         if (qs == hipSuccess) {
-            g->est_edges = std::max(g->est_edges, 1.5 * (double)g->h_counters[kMaxLevelEdges]);
-            g->est_log = std::max(g->est_log, 1.5 * (double)g->h_counters[kMaxLogRecords]);
+            // (only when the observation comes within 10 % of what the slabs hold: every new maximum would otherwise
+            //  re-allocate the workspace -- a device-wide synchronisation -- in the middle of a run of calls)
+            const double seen_e = (double)g->h_counters[kMaxLevelEdges], seen_l = (double)g->h_counters[kMaxLogRecords];
+            if (1.1 * seen_e > g->cur_e_est) g->est_edges = std::max(g->est_edges, 1.5 * seen_e);
+            if (g->cur_log_est > 0.0 && 1.1 * seen_l > g->cur_log_est) g->est_log = std::max(g->est_log, 1.5 * seen_l);
             if (g->last_call_rows > 0 && (double)g->h_counters[kRetryRows] > 0.02 * (double)g->last_call_rows)
                 g->est_edges = std::max(g->est_edges, 2.0 * g->cur_e_est);
         } else if (qs != hipErrorNotReady) {
@@ -769,8 +772,8 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     // grow the estimate the next call's slabs are sized from: 1.5 x the largest level / log seen so far
     // (gp_gfpush_device does the same, and the doubling after a call with > 2 % retried rows, when it starts)
     if (g->est_level_edges == 0) {
-        g->est_edges = std::max(g->est_edges, 1.5 * (double)s.max_level_edges);
-        g->est_log = std::max(g->est_log, 1.5 * (double)s.max_log_records);
+        if (1.1 * (double)s.max_level_edges > g->cur_e_est) g->est_edges = std::max(g->est_edges, 1.5 * (double)s.max_level_edges);
+        if (g->cur_log_est > 0.0 && 1.1 * (double)s.max_log_records > g->cur_log_est) g->est_log = std::max(g->est_log, 1.5 * (double)s.max_log_records);
     }
     s.diag_ticks_scan = (int64_t)g->h_counters[kTicksScan];
     s.diag_ticks_expand = (int64_t)g->h_counters[kTicksExpand];

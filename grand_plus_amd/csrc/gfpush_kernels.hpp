@@ -490,6 +490,65 @@ __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 ca
 #endif
 }
 
+// One 64-edge window of EXPAND into an LDS hash table, start to finish in gfx950 assembly: "has an edge" test, partition
+// filter (hash_b; skipped when parts == 1), home slot (hash_a), the compare-and-swap probing loop, ds_add_f64 of the share
+// for the lanes that found or claimed their slot, the sticky overflow flag for lanes that hit the probe limit.  ~32
+// instructions per window at 1.3 probes, 8 of them scalar; the compiler's version of the same C++ (nested exec save /
+// restore blocks, booleans moved through VGPRs, a uniform branch per condition) executed ~100, 40 of them scalar, and the
+// step loop of EXPAND is where a third of the kernel's instructions are issued.
+#ifndef GP_ASM_WINDOW
+#define GP_ASM_WINDOW 1
+#endif
+__device__ __forceinline__ void insert_window_asm(int* keys, double* vals, u32 cap, u32* flag, int col, double sh, u32 parts, u32 part)
+{
+    u32 t, h, slot, seen, st; u64 sv, ent;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_i32 vcc, -1, %[col]\n\t"                       // lanes that hold an edge
+        "s_cmp_eq_u32 %[parts], 1\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "v_mul_lo_u32 %[t], %[col], %[cb1]\n\t"                   // hash_b -> partition
+        "v_lshrrev_b32 %[h], 16, %[t]\n\t"
+        "v_xor_b32 %[t], %[h], %[t]\n\t"
+        "v_mul_lo_u32 %[t], %[t], %[cb2]\n\t"
+        "v_mul_hi_u32 %[t], %[t], %[parts]\n\t"
+        "v_cmpx_eq_u32 vcc, %[part], %[t]\n"
+        "3:\n\t"
+        "s_cbranch_execz 5f\n\t"
+        "s_mov_b64 %[ent], exec\n\t"
+        "v_mul_lo_u32 %[h], %[col], %[ca1]\n\t"                   // hash_a -> home slot
+        "v_lshrrev_b32 %[t], 15, %[h]\n\t"
+        "v_xor_b32 %[h], %[t], %[h]\n\t"
+        "v_mul_lo_u32 %[h], %[h], %[ca2]\n\t"
+        "v_mul_hi_u32 %[slot], %[h], %[capm]\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "1:\n\t"
+        "v_lshl_add_u32 %[t], %[slot], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[seen], %[t], %[emp], %[col]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmpx_ne_u32 vcc, %[seen], %[col]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[seen]\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[slot], %[st], %[slot]\n\t"
+        "s_add_u32 %[st], %[st], 1\n\t"
+        "s_cmp_le_u32 %[st], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "v_mov_b32 %[t], 1\n\t"                                   // probe limit reached: the lanes still searching give up
+        "v_mov_b32 %[h], %[fa]\n\t"
+        "ds_write_b32 %[h], %[t]\n"
+        "2:\n\t"
+        "s_andn2_b64 exec, %[ent], exec\n\t"                      // the lanes that found or claimed their slot
+        "v_lshl_add_u32 %[t], %[slot], 3, %[vb]\n\t"
+        "ds_add_f64 %[t], %[sh]\n"
+        "5:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t] "=&v"(t), [h] "=&v"(h), [slot] "=&v"(slot), [seen] "=&v"(seen), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
+        : [col] "v"(col), [sh] "v"(sh), [emp] "v"(kEmpty), [parts] "s"(parts), [part] "s"(part),
+          [ca1] "s"(0x9E3779B1u), [ca2] "s"(0x85EBCA77u), [cb1] "s"(0x7FEB352Du), [cb2] "s"(0x846CA68Bu),
+          [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
+}
+
 // Four inserts per lane with their probing chains INTERLEAVED (the four 64-edge windows of an EXPAND step).  One window's
 // chain is a sequence of dependent LDS round trips whose length is the LONGEST of its 64 lanes' probe sequences (4-7 probes
 // at the load factors of the peak levels), and a step ran four such chains one after the other: more than half of a wave's
@@ -1105,6 +1164,13 @@ __device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double*
 {
     u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
     edge_stream<BLOCK>(p, ctl, push, bt, n_ent, E, dry, [&](const int (&v)[4], const double (&sh)[4]) {
+#if GP_ASM_WINDOW && !GP_CHEAP_HASH
+        if (IN_LDS && !DIRECT) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) insert_window_asm(lkeys, lvals, cap, flag, v[w], sh[w], parts, part);         // graph.h:98
+            return;
+        }
+#endif
 #if GP_INSERT4
         if (IN_LDS && !DIRECT) {
             u64 act[4];

@@ -602,7 +602,6 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     const bool auto_shape = g->block_threads == 0 && g->lds_bytes == 0;
     const bool tiny = (double)g->n_nodes <= 0.75 * (double)((80 * 1024 - kCtlBytes) / 12);
     const bool sparse = g->nnz < 8 * g->n_nodes;
-    const bool fits_direct = (u64)g->n_nodes + 4 <= ((u64)((80 * 1024 - kCtlBytes) / 12) & ~3ull);
     bool two_per_cu = auto_shape && K <= 256 && (tiny || sparse || rmax >= 5e-6);
     int block_threads = 0, lds_bytes = 0, n_wg = 0;
     u32 lds_slots = 0;
@@ -611,8 +610,8 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         if (auto_shape) {
             // 12 waves per row: with the phases compiled as separate functions (32-66 VGPRs each) two 768-thread workgroups
             // fit a CU at 80 VGPRs without spilling the loops (round 3: MAG +11 %, Reddit +7 %, Pubmed +3 % over 2 x 512);
-            // graphs small enough for direct-indexed tables keep the 512-thread kernel that implements them
-            block_threads = two_per_cu ? (fits_direct && g->direct_tables ? 512 : 768) : 1024;
+            // (direct-indexed tables of small graphs are instantiated for both two-per-CU shapes: Cora +11 % at 768)
+            block_threads = two_per_cu ? 768 : 1024;
             lds_bytes = two_per_cu ? 80 * 1024 : 160 * 1024;
         } else {
             if (block_threads == 0) block_threads = 1024;
@@ -698,7 +697,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.diag_flags = g->diag_flags;
     kp.rows_distinct = g->rows_distinct && g->seedrow ? 1u : 0u;
     // direct-indexed level tables: the whole graph fits the table of the 512-thread kernel (Cora, Citeseer)
-    kp.direct = (block_threads == 512 && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
+    kp.direct = ((block_threads == 512 || block_threads == 768) && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
 
     auto launch = [&](int wgs) {

@@ -1865,6 +1865,9 @@ __device__ GP_PHASE_NOINLINE void phase_topk(u32 lds0, u32 row_lo, u32 row_hi, i
 #ifndef GP_MINW_1024
 #define GP_MINW_1024 4         // 8: two 1024-thread workgroups per CU with 64 VGPRs (tools/ab.sh experiments)
 #endif
+// direct-indexed level tables are instantiated for the two-workgroups-per-CU shapes only
+template <int BLOCK> constexpr bool kDirectOk = BLOCK == 512 || BLOCK == 768;
+
 template <int BLOCK>
 __device__ __forceinline__ void gfpush_rows()
 {
@@ -1979,7 +1982,7 @@ __device__ __forceinline__ void gfpush_rows()
                     if (share != 0.0) {
                         e_cur = seed_deg; n_ent_cur = 1;
                         seed_share = share;
-                        seedrow = p.rows_distinct && !p.force_global && !(BLOCK == 512 && p.direct) &&
+                        seedrow = p.rows_distinct && !p.force_global && !(kDirectOk<BLOCK> && p.direct) &&
                                   seed_deg <= (u32)(BLOCK / 64) * seedrow_slice<BLOCK>(C);
                         if (seedrow) {                       // level 1 needs neither the entry nor a table; its SCAN starts right behind this
                             if (tid == 0) { LevelCtr* n1 = &ctl->lc[1]; n1->dangling = 0.0; n1->n_dangling = 0; n1->alloc = 0ull; }   // block's barrier
@@ -2016,7 +2019,7 @@ __device__ __forceinline__ void gfpush_rows()
             bool in_lds = !p.force_global;
             u32 parts = 1, cap = 0;
             // direct-indexed tables (host sets p.direct only for the 512-thread kernel and N <= slots)
-            const bool direct = BLOCK == 512 && p.direct && in_lds;
+            const bool direct = kDirectOk<BLOCK> && p.direct && in_lds;
             if (direct) {
                 cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
             } else if (in_lds) {
@@ -2101,8 +2104,8 @@ __device__ __forceinline__ void gfpush_rows()
 #ifdef GP_DIAG_HEAVY
                         if (tid == 0) ctl->exp_c0 = clock64();
 #endif
-                        if (BLOCK == 512 && direct) {
-                            phase_expand<BLOCK, BLOCK == 512 ? 2 : 0>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
+                        if (kDirectOk<BLOCK> && direct) {
+                            phase_expand<BLOCK, kDirectOk<BLOCK> ? 2 : 0>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
                         } else if (in_lds) {
                             phase_expand<BLOCK, 0>(lds0, cap, (u32)cur, n_ent_cur, e_cur, part, np, has_dang_cur ? 1u : 0u, dang_cur, seed_key, 0u);
 #ifdef GP_DIAG

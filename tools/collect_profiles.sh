@@ -4,6 +4,7 @@
 # Every rocprofv3 pass runs under its own timeout (a failed pass can hang while finalizing).
 TAG=${1:-final}; OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
+export GRANDPLUS_SYNTH_CACHE=${GRANDPLUS_SYNTH_CACHE:-/dev/shm/gp_synth}
 mkdir -p $OUT
 # 1. kernel trace of the default bench line (MAG shape)
 timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows > $OUT/trace.log 2>&1

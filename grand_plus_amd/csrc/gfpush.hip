@@ -88,7 +88,7 @@ struct gp_graph {
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
-    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1;
+    int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
     double est_rmax = -1.0; int est_n_coef = 0;                            // the call parameters that estimate belongs to
@@ -542,6 +542,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         g->exact_stats = value ? 1 : 0;
     } else if (k == "direct_tables") {
         g->direct_tables = value ? 1 : 0;        // 0 = always hash (testing / A-B of the direct-indexed small-graph tables)
+    } else if (k == "solo_levels") {
+        g->solo_levels = value ? 1 : 0;          // 0 = small levels take EXPAND + SCAN of the whole workgroup like every other level (testing / A-B)
     } else if (k == "seedrow") {
         g->seedrow = value ? 1 : 0;              // 0 = level 1 through EXPAND and a table like every other level (testing / A-B)
     } else if (k == "diag_flags") {
@@ -696,6 +698,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.prune = g->exact_stats ? 0 : 1;
     kp.diag_flags = g->diag_flags;
     kp.rows_distinct = g->rows_distinct && g->seedrow ? 1u : 0u;
+    kp.solo = g->solo_levels ? 1u : 0u;
     // direct-indexed level tables: the whole graph fits the table of the 512-thread kernel (Cora, Citeseer)
     kp.direct = ((block_threads == 512 || block_threads == 768) && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
@@ -908,7 +911,7 @@ int replicate_part(gp_graph* g, int d) {
     q->packed = true; q->max_degree_bits = src->max_degree_bits; q->rows_distinct = src->rows_distinct;
     q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
     q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
-    q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges; q->seedrow = src->seedrow;
+    q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges; q->seedrow = src->seedrow; q->solo_levels = src->solo_levels;
     const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));

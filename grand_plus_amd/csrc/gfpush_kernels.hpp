@@ -111,6 +111,9 @@ constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts w
 #ifndef GP_EVEN_WALK
 #define GP_EVEN_WALK 0          // capacities that give every wave of SCAN the same number of 256-slot steps: MAG -1.3 %, Reddit -1.4 %, Pubmed -1.2 % (the smaller table costs more than the even walk saves)
 #endif
+#ifndef GP_SOLO
+#define GP_SOLO 1
+#endif
 #ifndef GP_BUCKET_MIN
 #define GP_BUCKET_MIN 3
 #endif
@@ -266,6 +269,7 @@ struct KParams {
     u32 lds_slots;
     int force_global;
     int prune;                            // 1: threshold-pruned reserve aggregation allowed (all coef >= 0)
+    u32 solo;                             // 1: levels of <= 256 edges from <= 64 entries are done by one wave (option "solo_levels")
     u32 rows_distinct;                    // 1: every CSR row holds strictly increasing column ids (checked at gp_graph_create): level 1 needs no table
     int direct;                           // 1: every level's table is indexed by node id (N <= lds_slots; 512-thread kernel only)
     // Two launches per call.  The first gives every workgroup a slab sized from an ESTIMATE of a row's needs; a row that
@@ -545,6 +549,51 @@ __device__ __forceinline__ void insert_window_asm(int* keys, double* vals, u32 c
         : [t] "=&v"(t), [h] "=&v"(h), [slot] "=&v"(slot), [seen] "=&v"(seen), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
         : [col] "v"(col), [sh] "v"(sh), [emp] "v"(kEmpty), [parts] "s"(parts), [part] "s"(part),
           [ca1] "s"(0x9E3779B1u), [ca2] "s"(0x85EBCA77u), [cb1] "s"(0x7FEB352Du), [cb2] "s"(0x846CA68Bu),
+          [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
+}
+
+// The same window insert for the one-wave small-level path: no partition filter, and the lane learns where its key lives
+// (`slot`) and whether it CLAIMED that slot (`seen` == kEmpty) -- the claimed slots ARE the level's frontier, so that path
+// never walks the table.  `seen` stays 0 in lanes without an edge.
+__device__ __forceinline__ void insert_window_solo(int* keys, double* vals, u32 cap, u32* flag, int col, double sh, u32& slot, int& seen)
+{
+    u32 t, h, st; u64 sv, ent;
+    slot = 0; seen = 0;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_i32 vcc, -1, %[col]\n\t"
+        "s_cbranch_execz 5f\n\t"
+        "s_mov_b64 %[ent], exec\n\t"
+        "v_mul_lo_u32 %[h], %[col], %[ca1]\n\t"
+        "v_lshrrev_b32 %[t], 15, %[h]\n\t"
+        "v_xor_b32 %[h], %[t], %[h]\n\t"
+        "v_mul_lo_u32 %[h], %[h], %[ca2]\n\t"
+        "v_mul_hi_u32 %[slot], %[h], %[capm]\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "1:\n\t"
+        "v_lshl_add_u32 %[t], %[slot], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[seen], %[t], %[emp], %[col]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmpx_ne_u32 vcc, %[seen], %[col]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[seen]\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[slot], %[st], %[slot]\n\t"
+        "s_add_u32 %[st], %[st], 1\n\t"
+        "s_cmp_le_u32 %[st], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "v_mov_b32 %[t], 1\n\t"
+        "v_mov_b32 %[h], %[fa]\n\t"
+        "ds_write_b32 %[h], %[t]\n"
+        "2:\n\t"
+        "s_andn2_b64 exec, %[ent], exec\n\t"
+        "v_lshl_add_u32 %[t], %[slot], 3, %[vb]\n\t"
+        "ds_add_f64 %[t], %[sh]\n"
+        "5:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t] "=&v"(t), [h] "=&v"(h), [slot] "+v"(slot), [seen] "+v"(seen), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
+        : [col] "v"(col), [sh] "v"(sh), [emp] "v"(kEmpty),
+          [ca1] "s"(0x9E3779B1u), [ca2] "s"(0x85EBCA77u),
           [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
         : "vcc", "scc", "memory");
 }
@@ -1724,6 +1773,119 @@ __device__ GP_PHASE_NOINLINE void phase_scan_seedrow(u32 lds0, u32 seed_start, u
     scan_level_dense<BLOCK, true>(p, w.ctl, &w.ctl->lc[1], w.lkeys, w.lvals, w.C, w.C, w.log_key, w.log_val,
                                   w.push2, w.bt2, c, do_push != 0, seed_start, seed_deg, share);
 }
+// A SMALL level -- at most 256 edges from at most 64 push-list entries -- done by ONE wave: EXPAND (one step: the whole push
+// list in the wave's lanes, four windows of column loads, inserts into a kMinCap-slot table), then SCAN straight over the
+// slots the inserts CLAIMED (no table walk), with nothing but the wave's own program order between them: LDS operations of
+// one wave execute in order, so the level needs no workgroup barrier inside.  The other waves skip the call and park at the
+// ONE barrier behind it (a level costs the row loop two barriers, two calls per wave and a table walk otherwise; levels 9
+// and 10 of a MAG row, the last levels of most recipes).  What it leaves behind is exactly what SCAN leaves: log records,
+// ctl->lc[lvl & 1], the next push list.  If an insert hits the probe limit (ctl->ovf), everything is undone and the caller
+// runs the level the general way.
+constexpr u32 kSoloEdges = 256, kSoloEntries = 64;
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u32 n_ent, u32 E, u32 has_dang, double dang, int seed_key,
+                                                   double c, u32 do_push_)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); lvl = uni(lvl); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); has_dang = uni(has_dang); dang = uni(dang);
+    seed_key = uni(seed_key); c = uni(c);
+    const bool do_push = uni(do_push_) != 0;
+    const WgView w = wg_view(p, lds0);
+    Ctl* ctl = w.ctl; int* lkeys = w.lkeys; double* lvals = w.lvals;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 cap = kMinCap;
+    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct;                 // wave 0's flag bytes
+    u32* list = (u32*)((unsigned char*)ctl + kCtlStruct + 64 * kFlatW);     // the flag areas of waves 1..5 (<= 257 claimed slots): those waves are parked
+    LevelCtr* nx = &ctl->lc[lvl & 1u];
+    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
+    PushEntry* push_nxt = w.push2 + (size_t)(cur ^ 1u) * p.push_cap;
+    u32* bt_nxt = w.bt2 + (size_t)(cur ^ 1u) * p.bt_cap;
+    // ---- EXPAND: one step
+    const PushEntry ent = push_cur[min(lane, n_ent - 1u)];
+    const u32 off = lane < n_ent ? ent.off : 0xFFFFFFFFu;
+    *(u32*)(wscr + 4 * lane) = 0u;
+    if (off > 0u && off < E) wscr[(off & 63u) * 4u + (off >> 6)] = 1;
+    asm volatile("" ::: "memory");            // the word is written by OTHER lanes
+    const u32 fl = *(const u32*)(wscr + 4 * lane);
+    u32 before = 0, n_list = 0;
+    int col[4]; double sh[4];
+    {
+        u32 e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool mine = ((fl >> (8 * q)) & 1u) != 0;
+            const u64 M = __ballot(mine);
+            e[q] = (before + lane_prefix(M) + (mine ? 1u : 0u)) << 2;
+            before += (u32)__popcll(M);
+        }
+        const u64 sbits = (u64)__double_as_longlong(ent.share);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)ent.rel);
+            const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)sbits);
+            const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)(sbits >> 32));
+            const u32 eq = 64u * (u32)q + lane;
+            col[q] = p.indices[eq < E ? rel_e + eq : (u32)p.nnz];            // graph.h:97
+            sh[q] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {             // the four windows, then the mass dangling nodes returned to the seed (graph.h:92)
+        if (q == 4 && !has_dang) break;
+        const int kq = q < 4 ? col[q] : (lane == 0 ? seed_key : -1);
+        const double vq = q < 4 ? sh[q] : dang;
+        u32 slot; int seen;
+        insert_window_solo(lkeys, lvals, cap, &ctl->ovf, kq, vq, slot, seen);
+        const bool fresh = kq >= 0 && seen == kEmpty;                       // this lane claimed the slot: a new frontier node
+        const u64 M = __ballot(fresh);
+        if (fresh) list[n_list + lane_prefix(M)] = slot;
+        n_list += (u32)__popcll(M);
+    }
+    asm volatile("" ::: "memory");
+    if (uni(ctl->ovf)) {                      // (practically never at load <= 0.35) undo: the claimed slots are all there is
+        for (u32 j = lane; j < n_list; j += 64u) { const u32 sl = list[j]; lkeys[sl] = kEmpty; lvals[sl] = 0.0; }
+        return;
+    }
+    // ---- SCAN over the claimed slots
+    const u32 lb = uni(ctl->log_count);
+    u32 st_push = 0, st_edges = 0, st_deg = 0;
+    for (u32 j = 0; j < n_list; j += 64u) {
+        const bool valid = j + lane < n_list;
+        int k = kEmpty; double r = 0.0;
+        if (valid) {
+            const u32 sl = list[j + lane];
+            k = lkeys[sl]; r = lvals[sl];
+            lkeys[sl] = kEmpty; lvals[sl] = 0.0;
+            const u32 li = lb + j + lane;                                   // graph.h:90 / :109
+            if ((u64)li < p.log_cap) { w.log_key[li] = k; w.log_val[li] = c * r; } else ctl->fail = 1;
+        }
+        if (!do_push) continue;
+        const u32 dq = (u32)k >> p.deg_shift;
+        const bool cand = valid && (dq == 0u || r >= p.rmax * (double)dq);
+        double share = 0.0; u32 len = 0, ds = 0;
+        if (cand) {
+            const int node = (int)((u32)k & p.node_mask);
+            ds = (u32)p.indptr[node]; const u32 deg = (u32)p.indptr[node + 1] - ds; ++st_deg;          // graph.h:43-45
+            if (deg == 0) {                                                                           // graph.h:91-93
+                __hip_atomic_fetch_add(&nx->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (r >= p.rmax * (double)deg) {                                                   // graph.h:94
+                ++st_push; st_edges += deg;
+                const double s_ = r / (double)deg;                                                    // graph.h:95
+                if (s_ != 0.0) { share = s_; len = deg; }
+            }
+        }
+        push_alloc(p, ctl, nx, push_nxt, bt_nxt, len, ds, share, (int)lane);
+    }
+    st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
+    if (lane == 0) {
+        ctl->log_count = lb + n_list;
+        if (n_list) stat_add(ctl, sFront, n_list);
+        if (st_deg) stat_add(ctl, sDeg, st_deg);
+        if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
+    }
+}
+
 template <int BLOCK>
 __device__ GP_PHASE_NOINLINE void phase_scan_hbm(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, double c, u32 do_push)
 {
@@ -2087,7 +2249,19 @@ __device__ __forceinline__ void gfpush_rows()
                 tk_expand += tkd[0]; tk_scan += tkd[1]; lv_passes += (u32)tkd[2];
 #endif
             }
-            if (!use_buckets && !uni(ctl->fail)) {
+            // a small level: one wave does it, the others park at one barrier (phase_solo_level)
+            bool solo_done = false;
+            if (GP_SOLO && in_lds && !direct && parts == 1 && !lvl_seedrow && !use_buckets && p.solo &&
+                e_cur <= kSoloEdges && n_ent_cur >= 1u && n_ent_cur <= kSoloEntries && !uni(ctl->fail)) {
+                GP_STAMP(t0);
+                if (wave_id() == 0)
+                    phase_solo_level<BLOCK>(lds0, (u32)lvl, (u32)cur, n_ent_cur, e_cur, has_dang_cur ? 1u : 0u, dang_cur, seed_key, c, do_push ? 1u : 0u);
+                GP_SYNC();
+                GP_STAMP(t2); GP_ACCUM(tk_scan, t0, t2);
+                if (!uni(ctl->ovf)) solo_done = true;
+                else { GP_SYNC(); if (tid == 0) ctl->ovf = 0; GP_SYNC(); }      // (undone by the wave: the general path takes the level)
+            }
+            if (!solo_done && !use_buckets && !uni(ctl->fail)) {
                 {
                     u32 part = 0, np = parts;
                     for (;;) {

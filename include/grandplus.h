@@ -168,6 +168,8 @@ int gp_reset_stats(gp_graph* g);
  *                      512-thread kernel -- Cora, Citeseer -- skip hashing altogether)
  *   "seedrow"         0 = level 1 of a row goes through EXPAND and a hash table like every other level (default 1: on graphs
  *                      whose CSR rows hold strictly increasing column ids the seed's neighbour list IS level 1's frontier)
+ *   "solo_levels"     0 = levels of <= 256 edges go through EXPAND + SCAN of the whole workgroup (default 1: one wave does such a
+ *                      level start to finish, the others park at one barrier)
  *   "diag_flags"      ignored by the product library; the diagnostic build (-DGP_DIAG) skips phases for
  *                      instruction attribution (bit 0: TOP-K) -- its results are then meaningless
  * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.

@@ -586,3 +586,35 @@ def test_level_one_from_the_seed_row_equals_the_table_path():
     got, _ = _run_gpu(ip, ix, [0, 1, 2, 3], coef, 0.0, 4)
     exp, _ = _oracle(ip, ix, [0, 1, 2, 3], coef, 0.0, 4)
     _assert_parity([0, 1, 2, 3], 4, got, exp)
+
+
+def test_small_levels_by_one_wave_equal_the_workgroup_path():
+    """Levels of <= 256 edges from <= 64 push-list entries are done by ONE wave (EXPAND, then SCAN over the slots its inserts
+    claimed, no barrier in between; option "solo_levels", default on).  Rows, exact counters and the oracle must agree with the
+    whole-workgroup path, on recipes whose rows consist mostly of such levels (high rmax), with dangling nodes, and on the
+    last level (no push)."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import make_coef
+    indptr, indices = synth.shape_csr("small")
+    seeds = synth.seeds(len(indptr) - 1, 1024)
+    for mode, order, rmax, K in (("ppr", 8, 1e-3, 16), ("ppr", 10, 1e-4, 32), ("avg", 3, 2e-3, 8), ("ppr", 6, 1e-5, 16)):
+        coef = make_coef(mode, order, 0.2)
+        on, st_on = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"exact_stats": 1})
+        off, st_off = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"exact_stats": 1, "solo_levels": 0, "seedrow": 0})
+        exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
+        _assert_parity(seeds, K, on, exp)
+        _assert_parity(seeds, K, off, exp)
+        for k in ("pushes", "edges", "filled", "support", "frontier", "degree_lookups"):
+            assert st_on[k] == st_off[k], (k, st_on[k], st_off[k])
+        assert st_on["pushes"] == ost["pushes"] and st_on["edges"] == ost["edges"] and st_on["frontier"] == ost["frontier_sum"]
+    # dangling nodes return their mass to the seed inside a small level (graph.h:91-93): a directed chain with sinks
+    n = 64
+    rows = [[(i + 1) % n, (i + 7) % n] if i % 5 else [] for i in range(n)]
+    ip = np.zeros(n + 1, np.int32); ip[1:] = np.cumsum([len(r) for r in rows])
+    ix = np.array([c for r in rows for c in sorted(r)], np.int32)
+    coef = make_coef("ppr", 6, 0.3)
+    sd = np.arange(n, dtype=np.int32)
+    got, st = _run_gpu(ip, ix, sd, coef, 0.0, 8, fill=(-1, -1, -1.0), options={"exact_stats": 1})
+    exp, ost = _oracle(ip, ix, sd, coef, 0.0, 8, fill=(-1, -1, -1.0))
+    _assert_parity(sd, 8, got, exp, fill=(-1, -1, -1.0))
+    assert st["pushes"] == ost["pushes"] and st["frontier"] == ost["frontier_sum"]

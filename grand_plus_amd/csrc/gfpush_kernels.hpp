@@ -1781,7 +1781,10 @@ __device__ GP_PHASE_NOINLINE void phase_scan_seedrow(u32 lds0, u32 seed_start, u
 // and 10 of a MAG row, the last levels of most recipes).  What it leaves behind is exactly what SCAN leaves: log records,
 // ctl->lc[lvl & 1], the next push list.  If an insert hits the probe limit (ctl->ovf), everything is undone and the caller
 // runs the level the general way.
-constexpr u32 kSoloEdges = 256, kSoloEntries = 64;
+#ifndef GP_SOLO_EDGES
+#define GP_SOLO_EDGES 256
+#endif
+constexpr u32 kSoloEdges = GP_SOLO_EDGES, kSoloEntries = 64;
 template <int BLOCK>
 __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u32 n_ent, u32 E, u32 has_dang, double dang, int seed_key,
                                                    double c, u32 do_push_)
@@ -1793,7 +1796,7 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
     const WgView w = wg_view(p, lds0);
     Ctl* ctl = w.ctl; int* lkeys = w.lkeys; double* lvals = w.lvals;
     const u32 lane = threadIdx.x & 63u;
-    const u32 cap = kMinCap;
+    const u32 cap = kSoloEdges > 256u ? 2048u : kMinCap;
     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct;                 // wave 0's flag bytes
     u32* list = (u32*)((unsigned char*)ctl + kCtlStruct + 64 * kFlatW);     // the flag areas of waves 1..5 (<= 257 claimed slots): those waves are parked
     LevelCtr* nx = &ctl->lc[lvl & 1u];
@@ -1803,11 +1806,14 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
     // ---- EXPAND: one step
     const PushEntry ent = push_cur[min(lane, n_ent - 1u)];
     const u32 off = lane < n_ent ? ent.off : 0xFFFFFFFFu;
+    u32 n_list = 0;
+    for (u32 t0 = 0; t0 < E; t0 += 256u) {
+    const u32 t1 = min(E, t0 + 256u);
     *(u32*)(wscr + 4 * lane) = 0u;
-    if (off > 0u && off < E) wscr[(off & 63u) * 4u + (off >> 6)] = 1;
+    if (off > t0 && off < t1) { const u32 pos = off - t0; wscr[(pos & 63u) * 4u + (pos >> 6)] = 1; }
     asm volatile("" ::: "memory");            // the word is written by OTHER lanes
     const u32 fl = *(const u32*)(wscr + 4 * lane);
-    u32 before = 0, n_list = 0;
+    u32 before = (u32)__popcll(__ballot(off <= t0)) - 1u;
     int col[4]; double sh[4];
     {
         u32 e[4];
@@ -1824,14 +1830,14 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
             const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)ent.rel);
             const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)sbits);
             const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)(sbits >> 32));
-            const u32 eq = 64u * (u32)q + lane;
-            col[q] = p.indices[eq < E ? rel_e + eq : (u32)p.nnz];            // graph.h:97
+            const u32 eq = t0 + 64u * (u32)q + lane;
+            col[q] = p.indices[eq < t1 ? rel_e + eq : (u32)p.nnz];           // graph.h:97
             sh[q] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
         }
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {             // the four windows, then the mass dangling nodes returned to the seed (graph.h:92)
-        if (q == 4 && !has_dang) break;
+        if (q == 4 && (!has_dang || t1 < E)) break;
         const int kq = q < 4 ? col[q] : (lane == 0 ? seed_key : -1);
         const double vq = q < 4 ? sh[q] : dang;
         u32 slot; int seen;
@@ -1840,6 +1846,7 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
         const u64 M = __ballot(fresh);
         if (fresh) list[n_list + lane_prefix(M)] = slot;
         n_list += (u32)__popcll(M);
+    }
     }
     asm volatile("" ::: "memory");
     if (uni(ctl->ovf)) {                      // (practically never at load <= 0.35) undo: the claimed slots are all there is

@@ -605,6 +605,14 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     const bool tiny = (double)g->n_nodes <= 0.75 * (double)((80 * 1024 - kCtlBytes) / 12);
     const bool sparse = g->nnz < 8 * g->n_nodes;
     bool two_per_cu = auto_shape && K <= 256 && (tiny || sparse || rmax >= 5e-6);
+    // Three 512-thread workgroups per CU (52 KB of LDS each, 6 waves per SIMD at 80 VGPRs) for the citation-graph
+    // shape: levels of a few thousand edges fit the small table in one or two partitions, and a third resident row
+    // hides more of each row's barriers and latency than the extra partition costs.  Measured on MI355X (round 3,
+    // 65 536 rows): Pubmed +13 %, Cora +10 % over 2 x 768; MAG-shape -9 % and Reddit-shape -15 % (3+ partitions at
+    // the peak levels and a pruned TOP-K table too small for the reserve log), which is why the rule is the edge
+    // density of the graph, not the recipe.
+    const bool small_direct = (double)g->n_nodes + 4 <= (double)(((kThreeLds - kCtlBytes) / 12) & ~3);
+    bool three_per_cu = two_per_cu && K <= 128 && (small_direct || sparse);
     int block_threads = 0, lds_bytes = 0, n_wg = 0;
     u32 lds_slots = 0;
     for (;;) {
@@ -613,8 +621,8 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
             // 12 waves per row: with the phases compiled as separate functions (32-66 VGPRs each) two 768-thread workgroups
             // fit a CU at 80 VGPRs without spilling the loops (round 3: MAG +11 %, Reddit +7 %, Pubmed +3 % over 2 x 512);
             // (direct-indexed tables of small graphs are instantiated for both two-per-CU shapes: Cora +11 % at 768)
-            block_threads = two_per_cu ? 768 : 1024;
-            lds_bytes = two_per_cu ? 80 * 1024 : 160 * 1024;
+            block_threads = three_per_cu ? 512 : two_per_cu ? 768 : 1024;
+            lds_bytes = three_per_cu ? kThreeLds : two_per_cu ? 80 * 1024 : 160 * 1024;
         } else {
             if (block_threads == 0) block_threads = 1024;
             if (lds_bytes == 0) lds_bytes = 160 * 1024;
@@ -642,6 +650,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         if (rc) return rc;
         // the workspace budget could not hold two workgroups per CU: one big workgroup per CU is better than
         // a half-empty chip
+        if (three_per_cu && g->ws.est.n_wg < n_wg && g->ws.est.n_wg < 3 * g->num_cus) { three_per_cu = false; continue; }
         if (two_per_cu && g->ws.est.n_wg < n_wg && g->ws.est.n_wg < 2 * g->num_cus) { two_per_cu = false; continue; }
         break;
     }

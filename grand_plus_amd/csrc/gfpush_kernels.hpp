@@ -93,6 +93,7 @@ constexpr int    kCtlStruct  = 4096;    // (diagnostic build: + per-barrier-site
 constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic LDS ...
 #endif
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (edge_stream)
+constexpr int    kThreeLds   = 53248;   // dynamic LDS of a workgroup when three share a CU (160 KB / 3, allocation granularity)
 #ifndef GP_MIN_CAP
 #define GP_MIN_CAP 1024
 #endif
@@ -1683,11 +1684,11 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
 }
 
 // ---------------------------------------------------------------- the kernel
-// Register budget: 1024 threads = 4 waves/SIMD = 128 VGPRs.  The 512- and 256-thread forms are
-// built for the SAME 4 waves/SIMD so that 2 (resp. 4) workgroups can share a CU and overlap
+// Register budget: 1024 threads = 4 waves/SIMD = 128 VGPRs.  The 768- and 512-thread forms are built for
+// 6 waves/SIMD (80 VGPRs) so that two 768-thread or three 512-thread workgroups share a CU and overlap
 // one row's barriers and memory stalls with another row's work.
 #ifndef GP_MINW_512
-#define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
+#define GP_MINW_512 6          // three 512-thread workgroups per CU (6 waves per SIMD, 80 VGPRs); 4: two with 128 VGPRs
 #endif
 #ifndef GP_MINW_768
 #define GP_MINW_768 6          // two 768-thread workgroups per CU (6 waves per SIMD, 80 VGPRs)
@@ -2021,19 +2022,6 @@ __device__ GP_PHASE_NOINLINE void phase_topk(u32 lds0, u32 row_lo, u32 row_hi, i
                     (long long)(((u64)row_hi << 32) | row_lo), seed, seg_begin, seg_len, n_levels, 0 GP_SUB_ARGS);
 }
 
-// ---------------------------------------------------------------- the kernel
-// Register budget: 1024 threads = 4 waves/SIMD = 128 VGPRs.  The 512- and 256-thread forms are
-// built for the SAME 4 waves/SIMD so that 2 (resp. 4) workgroups can share a CU and overlap
-// one row's barriers and memory stalls with another row's work.
-#ifndef GP_MINW_512
-#define GP_MINW_512 4          // 2: one 512-thread workgroup per CU with 256 VGPRs (tools/ab.sh experiments)
-#endif
-#ifndef GP_MINW_768
-#define GP_MINW_768 6          // two 768-thread workgroups per CU (6 waves per SIMD, 80 VGPRs)
-#endif
-#ifndef GP_MINW_1024
-#define GP_MINW_1024 4         // 8: two 1024-thread workgroups per CU with 64 VGPRs (tools/ab.sh experiments)
-#endif
 // direct-indexed level tables are instantiated for the two-workgroups-per-CU shapes only
 template <int BLOCK> constexpr bool kDirectOk = BLOCK == 512 || BLOCK == 768;
 

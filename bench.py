@@ -243,6 +243,16 @@ def run_rank(args) -> int:
     t0 = time.perf_counter()
     indptr, indices = load_graph(source, threads)
     n_nodes = len(indptr) - 1
+    relabel_inv = None
+    if os.environ.get("GRANDPLUS_EXP_RELABEL"):          # experiment: node ids in order of descending degree
+        deg = np.diff(indptr)
+        perm = np.argsort(-deg, kind="stable")
+        relabel_inv = np.empty(n_nodes, dtype=np.int32); relabel_inv[perm] = np.arange(n_nodes, dtype=np.int32)
+        new_deg = deg[perm]
+        new_indptr = np.zeros(n_nodes + 1, dtype=indptr.dtype); np.cumsum(new_deg, out=new_indptr[1:])
+        src = np.repeat(indptr[perm].astype(np.int64) - new_indptr[:-1].astype(np.int64), new_deg) + np.arange(len(indices), dtype=np.int64)
+        indices = np.ascontiguousarray(relabel_inv[indices[src]]); indptr = new_indptr
+        del src, deg, perm, new_deg
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     try:
@@ -271,6 +281,8 @@ def run_rank(args) -> int:
     S_step = per * world
     n_steps_total = args.warmup + args.steps
     all_seeds = make_seeds(source, n_nodes, S_step * n_steps_total)
+    if relabel_inv is not None:
+        all_seeds = np.ascontiguousarray(relabel_inv[all_seeds])
     # this rank's shard of every step's batch, resident in HBM before timing starts
     shards = []
     for i in range(n_steps_total):

@@ -605,14 +605,12 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     const bool tiny = (double)g->n_nodes <= 0.75 * (double)((80 * 1024 - kCtlBytes) / 12);
     const bool sparse = g->nnz < 8 * g->n_nodes;
     bool two_per_cu = auto_shape && K <= 256 && (tiny || sparse || rmax >= 5e-6);
-    // Three 512-thread workgroups per CU (52 KB of LDS each, 6 waves per SIMD at 80 VGPRs) for the citation-graph
-    // shape: levels of a few thousand edges fit the small table in one or two partitions, and a third resident row
-    // hides more of each row's barriers and latency than the extra partition costs.  Measured on MI355X (round 3,
-    // 65 536 rows): Pubmed +13 %, Cora +10 % over 2 x 768; MAG-shape -9 % and Reddit-shape -15 % (3+ partitions at
-    // the peak levels and a pruned TOP-K table too small for the reserve log), which is why the rule is the edge
-    // density of the graph, not the recipe.
-    const bool small_direct = (double)g->n_nodes + 4 <= (double)(((kThreeLds - kCtlBytes) / 12) & ~3);
-    bool three_per_cu = two_per_cu && K <= 128 && (small_direct || sparse);
+    // Three 512-thread workgroups per CU (52 KB of LDS each, 6 waves per SIMD at 80 VGPRs): a third resident row hides
+    // more of each row's barriers and latency than the smaller table costs in extra hash partitions, once TOP-K no
+    // longer falls off a cliff at that size (its histogram and tie bucket now live inside the aggregation table's bytes
+    // and tau is read off a 16x finer histogram).  Measured on MI355X (round 3, 65 536 rows) against 2 x 768 x 80 KB:
+    // MAG-shape +2.9 %, Reddit-shape +1.3 %, Pubmed +13 %, Cora +10 %.  K > 128 keeps 2 x 768 (sel[K] eats the table).
+    bool three_per_cu = two_per_cu && K <= 128;
     int block_threads = 0, lds_bytes = 0, n_wg = 0;
     u32 lds_slots = 0;
     for (;;) {
@@ -628,12 +626,13 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
             if (lds_bytes == 0) lds_bytes = 160 * 1024;
         }
         lds_slots = (u32)((lds_bytes - kCtlBytes) / 12) & ~3u;     // multiple of 4: 128-bit LDS accesses on both arrays
-        // TOP-K carves hist[4096] | sel[K] | tie[kBucketCap] out of the table region and aggregates in what is
+        // TOP-K carves sel[K] out of the table region and aggregates in what is
         // left; like every LDS table that aggregation table needs >= kMinCap slots (home_lds: cap - kProbeSpan)
-        const size_t topk_fixed = kTopkBins * 4 + 16 * (size_t)K + 16 * (size_t)kBucketCap;
-        if ((size_t)lds_slots * 12 < topk_fixed + 12 * (size_t)kMinCap)
+        const size_t topk_fixed = 16 * (size_t)K;
+        const size_t topk_region = std::max<size_t>(12 * (size_t)kMinCap, kTopkBins * 4 + 16 * (size_t)kBucketCap);   // table, or histogram + compacted bucket
+        if ((size_t)lds_slots * 12 < topk_fixed + topk_region)
             return fail(GP_ERR_INVALID_ARG, "lds_bytes = %d too small for K = %d (top-K needs %zu bytes of LDS)",
-                        lds_bytes, K, topk_fixed + 12 * (size_t)kMinCap + kCtlBytes);
+                        lds_bytes, K, topk_fixed + topk_region + kCtlBytes);
 
         int per_cu = 1;
         switch (block_threads) {

@@ -1334,7 +1334,7 @@ __device__ __forceinline__ void load_log_records(const int* log_key, const doubl
 }
 
 // RESERVE + TOP-K of one row (graph.h:111-126).  `scratch` is the whole LDS table region:
-//   hist[4096] u32 | sel[K] | tie[kBucketCap] | agg = { vals f64[CA], keys i32[CA] }  (re-used as big[] of Cand)
+//   sel[K] | agg = { vals f64[CA], keys i32[CA] }  (re-used as { hist[4096] u32, then tie[kBucketCap] } | big[] of Cand)
 // 1. The reserve log is summed per node in the LDS table `agg` (one partition of the keys at
 //    a time when the log is long); each occupied slot is a node of the reserve map.  Values
 //    > 0 (graph.h:121) become candidates: written to `cand` and counted in the histogram of
@@ -1348,16 +1348,19 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
                                          int /*unused*/ GP_SUB_PARAMS)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)wave_id();
-    u32*  hist = (u32*)scratch;                                      // [kTopkBins]
-    Cand* sel  = (Cand*)(scratch + kTopkBins * sizeof(u32));         // [K]
-    Cand* tie  = sel + p.K;                                          // [kBucketCap]
-    unsigned char* region = (unsigned char*)(tie + kBucketCap);
+    Cand* sel  = (Cand*)scratch;                                     // [K]
+    unsigned char* region = (unsigned char*)(sel + p.K);
     const u32 region_bytes = scratch_bytes - (u32)(region - scratch);
     const u32 CA = region_bytes / 12;
     double* avals = (double*)region;
     int* akeys = (int*)(region + 8 * (size_t)CA);
-    Cand* big = (Cand*)region;
-    const u32 big_cap = region_bytes / (u32)sizeof(Cand);
+    // the select runs after the last aggregation table has been turned into candidates, so its digit histogram, the
+    // tie bucket and the compacted bucket share the table's bytes: 20 KB more table (1 700 slots) for the pruned aggregation
+    u32*  hist = (u32*)region;                                       // [kTopkBins]
+    Cand* tie  = (Cand*)region;                                      // [kBucketCap]: filled after the last histogram was read
+    static_assert(kBucketCap * sizeof(Cand) <= kTopkBins * sizeof(u32), "the tie bucket lives in the histogram's bytes");
+    Cand* big = (Cand*)(region + kTopkBins * sizeof(u32));
+    const u32 big_cap = (region_bytes - kTopkBins * (u32)sizeof(u32)) / (u32)sizeof(Cand);
     const u32 n_log = ctl->log_count;
     const u32 K = (u32)p.K;
 
@@ -1398,15 +1401,17 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
     // K-th largest total.  A node all of whose (<= n_levels) records are below tau/n_levels sums
     // to less than tau and cannot be selected.  Pass A claims table slots only for nodes owning a
     // record >= tau/n_levels, pass B adds ALL records of claimed nodes (read-only probe).  tau is
-    // taken as the lower edge of the binade holding that K-th record (one histogram pass).
+    // taken as the lower edge of the 1/16-binade counter holding that K-th record (one histogram pass).
     bool pruned_done = false;
     u32 live_nodes = 0;
     if (p.prune && seg_len >= 2 * K && n_levels >= 1) {
-        // Binade histogram of the segment in the 64 words of ctl->bcnt (free outside bucketed levels):
-        // records are <= 1, so bin b = 1023 - biased exponent counts [2^-b, 2^-b+1); bin 63 also takes
-        // everything smaller and then gives no threshold.  (A 4096-bin sign+exponent histogram in the
-        // scratch LDS did the same at the price of clearing and scanning 4096 words per row.)
-        if (tid < 64) ctl->bcnt[tid] = 0;
+        // Histogram of the segment's records by binade and the top 4 mantissa bits: 64 x 16 counters at the start
+        // of the (idle) table region, indexed so that a larger value has a smaller index.  Records are <= 1, so
+        // binade b = 1023 - biased exponent holds [2^-b, 2^-b+1); the last binade also takes everything smaller and
+        // then gives no threshold.  tau = the lower edge of the counter holding the K-th largest record: within
+        // 6 % of it (the binade counters alone gave up to a factor 2, which claimed ~1.4x the nodes).
+        u32* fine = hist;
+        for (u32 i = tid; i < 1024u; i += BLOCK) fine[i] = 0;
         if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
         GP_SYNC();
         for (u32 base = 0; base < seg_len; base += 8 * BLOCK) {              // 8 loads in flight per thread
@@ -1419,23 +1424,34 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (vv[u] > 0.0) {
-                    const int e = 1023 - (int)((u64)__double_as_longlong(vv[u]) >> 52);
-                    __hip_atomic_fetch_add(&ctl->bcnt[(u32)min(max(e, 0), 63)], 1u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const u64 bits = (u64)__double_as_longlong(vv[u]);
+                    const int e = 1023 - (int)(bits >> 52);
+                    const u32 m4 = (u32)(bits >> 48) & 15u;
+                    const u32 idx = e < 0 ? 15u : e > 63 ? 1023u : (u32)e * 16u + (15u - m4);   // out of range: the lowest counter of the end binade
+                    __hip_atomic_fetch_add(&fine[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
         }
         GP_SYNC();
         if (wave == 0) {
-            const u32 incl = wave_incl_scan(ctl->bcnt[lane], lane);          // records >= 2^-lane
+            u32 c[16], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { c[j] = fine[16 * lane + j]; sum += c[j]; }
+            const u32 incl = wave_incl_scan(sum, lane);                      // records >= 2^-lane
             const u64 m = __ballot(incl >= K);
-            if (lane == 0) ctl->tk_bin = m ? (u32)__ffsll((long long)m) - 1u : 0xFFFFFFFFu;
+            const u32 need = K - (incl - sum);                               // how many of this binade's records are still wanted
+            u32 acc = 0, jsel = 15; bool found = false;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { acc += c[j]; if (!found && acc >= need) { jsel = (u32)j; found = true; } }
+            if (m == 0) { if (lane == 0) ctl->tk_bin = 0xFFFFFFFFu; }
+            else if (lane == __ffsll((long long)m) - 1) ctl->tk_bin = 16u * (u32)lane + jsel;
         }
         GP_SYNC();
-        const u32 binade = ctl->tk_bin;
+        const u32 fsel = ctl->tk_bin;
         GP_SYNC();
+        const u32 binade = fsel == 0xFFFFFFFFu ? 63u : fsel >> 4;
         const u32 bin = binade >= 63u ? 0u : 1023u - binade;                 // biased exponent of tau; 0 = no threshold
         if (bin != 0xFFFFFFFFu && bin != 0) {
-            const double tau = __longlong_as_double((long long)((u64)bin << 52));
+            const double tau = __longlong_as_double((long long)(((u64)bin << 52) | ((u64)(15u - (fsel & 15u)) << 48)));
             const double thr = tau / (double)n_levels * 0.99999;
             for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
             GP_SYNC();

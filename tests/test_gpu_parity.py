@@ -511,16 +511,23 @@ def test_workspace_is_sized_from_estimates_not_from_the_rmax_bound():
 
 
 def test_lds_budget_too_small_for_topk_is_rejected():
-    """lds_bytes near 40 KB with a large K left the top-K aggregation table smaller than a probe span."""
+    """an lds_bytes near 40 KB with a large K would leave the top-K aggregation table smaller than a probe
+    span: refused.  (Round 3: the select's histogram and tie bucket live inside the aggregation table's bytes, so
+    45 056 bytes now hold K = 1000, which they did not before; those rows must be the oracle's.)"""
     from grand_plus_amd import Graph, synth
     indptr, indices = synth.shape_csr("tiny")
     g = Graph(indptr, indices, 0)
-    g.set_option("block_threads", 256); g.set_option("lds_bytes", 45056)
+    g.set_option("block_threads", 256); g.set_option("lds_bytes", 40960)
     seeds = synth.seeds(len(indptr) - 1, 8)
     K = 1000
+    coef = np.array([0.3, 0.3, 0.4])
     row = np.zeros(8 * K, np.int32); col = np.zeros(8 * K, np.int32); val = np.zeros(8 * K)
     with pytest.raises(ValueError, match="too small for K"):
-        g.gfpush_omp(seeds, row, col, val, np.array([0.5, 0.5]), 1e-4, K)
+        g.gfpush_omp(seeds, row, col, val, coef, 1e-6, K)
+    g.set_option("lds_bytes", 45056)
+    g.gfpush_omp(seeds, row, col, val, coef, 1e-6, K)
+    exp, _ = _oracle(indptr, indices, seeds, coef, 1e-6, K)
+    _assert_parity(seeds, K, (row, col, val), exp)
 
 
 def test_multi_gpu_handle_one_call_uses_every_gpu():

@@ -94,6 +94,15 @@ constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic
 #endif
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (edge_stream)
 constexpr int    kThreeLds   = 53248;   // dynamic LDS of a workgroup when three share a CU (160 KB / 3, allocation granularity)
+#ifndef GP_HEAVY_USE
+#define GP_HEAVY_USE 1
+#endif
+#ifndef GP_HEAVY_STORE
+#define GP_HEAVY_STORE 1
+#endif
+#ifndef GP_HEAVY
+#define GP_HEAVY 1                 // TOP-K threshold computed during the level loop + heavy list (0: TOP-K sweeps the log for claims)
+#endif
 #ifndef GP_MIN_CAP
 #define GP_MIN_CAP 1024
 #endif
@@ -136,7 +145,8 @@ struct Cand      { u64 bits;  int key; int pad;  };      // 16 B  top-K candidat
 struct LevelCtr {
     double dangling;      // mass returned to the seed by dangling nodes
     u32 n_dangling;       // how many dangling nodes were drained
-    u32 pad0;
+    u32 n_rec;            // reserve-log records of the level.  The level loop reads THIS after the level's last barrier, never
+                          // ctl->log_count: wave 0 may already be adding the next (one-wave) level's records to that one
     u64 alloc;            // next level's push list: entries so far (low half) and edges so far (high half) -- ONE atomic hands a wave
                           // both its entry indices and its edge offsets, so the list is ordered by `off` however the waves interleave
     u64 pad1;
@@ -165,6 +175,15 @@ struct Ctl {
     u64 st_row[12];       // statistics of the row in flight: added to st[] when the row completes, dropped when it is handed to the retry launch
     double coef[kCoefLds]; // the first coefficients of the recipe: every level starts by reading its own (a global load there is a
                           // dependent round trip on the row's critical path, 11 of them per MAG row)
+    // TOP-K threshold known early (phase_tau, after the first level with >= 2K records): every later SCAN notes the keys of
+    // the records >= thr_early in the "heavy list" (the idle candidate buffer), so TOP-K claims from a few hundred keys
+    // instead of sweeping the whole reserve log once more
+    double thr_early;     // +inf: not known (yet) -- no record qualifies
+    double tau_early;     // the proven lower bound on the K-th largest total (0: none)
+    u32 n_heavy;          // keys noted so far
+    u32 heavy_from;       // first reserve-log record covered by the heavy list
+    u32 heavy_ovf;        // the list outgrew its buffer: TOP-K sweeps the log as before
+    u32 pad_heavy;
 #ifdef GP_DIAG
     u64 lvl_acc[16][6];   // per level: expand ticks, scan ticks, edges, frontier nodes, push entries, table passes (flushed once per workgroup)
     u64 row_acc[4];       // per row: prologue, level 0, level loop outside EXPAND/SCAN, table restore (ticks)
@@ -780,6 +799,22 @@ __device__ __forceinline__ void push_alloc(KP p, Ctl* ctl, LevelCtr* nx, PushEnt
     }
 }
 
+// ---------------------------------------------------------------- heavy list (see Ctl::thr_early)
+struct Heavy { int* keys; u32 cap; double thr; };
+__device__ __forceinline__ Heavy heavy_view(KP p, Ctl* ctl) {
+    Heavy h;
+    h.keys = (int*)(p.cand + (size_t)blockIdx.x * p.cand_cap);                       // idle until TOP-K turns tables into candidates
+    h.cap = (u32)min((u64)0xFFFFFFFFu, 4ull * p.cand_cap);
+    h.thr = uni(ctl->thr_early);
+    return h;
+}
+__device__ __forceinline__ void heavy_note(Ctl* ctl, const Heavy& h, int k, double val) {
+    if (val >= h.thr) {                                                               // ~3 % of the records
+        const u32 hi = __hip_atomic_fetch_add(&ctl->n_heavy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (hi < h.cap) { if (GP_HEAVY_STORE) h.keys[hi] = k; } else ctl->heavy_ovf = 1u;
+    }
+}
+
 // ---------------------------------------------------------------- SCAN (slot-walking form)
 // Drains the residue table of one level (or one partition of it).  U slots per thread are
 // handled per round so that the indptr loads of all U nodes are in flight together.
@@ -792,6 +827,7 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
 {
     const int tid = threadIdx.x, lane = tid & 63;
     u32 st_push = 0, st_edges = 0, st_front = 0, st_deg = 0;        // this thread, this level
+    const Heavy hv = heavy_view(p, ctl);
     const u32 wave_first = wave_id() * 64u;
     for (u32 base = 0; base < cap; base += BLOCK * U) {
         if (base + wave_first >= cap) break;            // wave-uniform: nothing left for this wave
@@ -844,7 +880,7 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
         for (int u = 0; u < U; ++u) {
             if (occ[u]) {
                 ++st_front;
-                if (li[u] < p.log_cap) { log_key[li[u]] = k[u]; log_val[li[u]] = c * r[u]; }
+                if (li[u] < p.log_cap) { log_key[li[u]] = k[u]; log_val[li[u]] = c * r[u]; heavy_note(ctl, hv, k[u], c * r[u]); }
                 else ctl->fail = 1;
             }
         }
@@ -869,7 +905,7 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
     }
     st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_front = wave_sum32(st_front); st_deg = wave_sum32(st_deg);
     if (lane == 0) {
-        if (st_front) stat_add(ctl, sFront, st_front);
+        if (st_front) { stat_add(ctl, sFront, st_front); __hip_atomic_fetch_add(&nx->n_rec, st_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
         if (st_deg) stat_add(ctl, sDeg, st_deg);
         if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
     }
@@ -901,6 +937,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63;
     u32 st_push = 0, st_edges = 0, st_deg = 0;                      // this thread, this level
+    const Heavy hv = heavy_view(p, ctl);
     // Every wave owns ONE contiguous range of the table (a multiple of 256 slots) per level: it first
     // compacts the whole range, then processes its nodes.  The steps of (c) each end in a wait for
     // their indptr loads (and, vmcnt being shared, for the stores before them), so a level costs a
@@ -949,7 +986,10 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
 #endif
     if (tot != 0) {
         u32 lb = 0;
-        if (lane == 0) lb = __hip_atomic_fetch_add(&ctl->log_count, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) {
+            lb = __hip_atomic_fetch_add(&ctl->log_count, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&nx->n_rec, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         lb = (u32)__builtin_amdgcn_readfirstlane((int)lb);
         // (c) every node: reserve record + the cheap part of the push test (the degree rides in the key).
         //     Nodes that may push (~8 % on the power-law shapes) are compacted once more, to the front of
@@ -968,7 +1008,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
                     lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
                     // reserve log: one (node, coef*r) record per frontier node          graph.h:90 / :109
                     const u32 li = lb + idx;
-                    if (li < p.log_cap) { log_key[li] = k[v]; log_val[li] = c * r[v]; }
+                    if (li < p.log_cap) { log_key[li] = k[v]; log_val[li] = c * r[v]; heavy_note(ctl, hv, k[v], c * r[v]); }
                     else ctl->fail = 1;
                     // exact degree known and the test fails => dropped without touching memory   (graph.h:94);
                     // a saturated field still says deg >= deg_sat, so r < rmax*deg_sat cannot push either
@@ -1405,53 +1445,63 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
     bool pruned_done = false;
     u32 live_nodes = 0;
     if (p.prune && seg_len >= 2 * K && n_levels >= 1) {
-        // Histogram of the segment's records by binade and the top 4 mantissa bits: 64 x 16 counters at the start
-        // of the (idle) table region, indexed so that a larger value has a smaller index.  Records are <= 1, so
-        // binade b = 1023 - biased exponent holds [2^-b, 2^-b+1); the last binade also takes everything smaller and
-        // then gives no threshold.  tau = the lower edge of the counter holding the K-th largest record: within
-        // 6 % of it (the binade counters alone gave up to a factor 2, which claimed ~1.4x the nodes).
-        u32* fine = hist;
-        for (u32 i = tid; i < 1024u; i += BLOCK) fine[i] = 0;
-        if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
-        GP_SYNC();
-        for (u32 base = 0; base < seg_len; base += 8 * BLOCK) {              // 8 loads in flight per thread
-            double vv[8];
+        // (phase_tau already did all of this for the rows whose threshold level was not their last one)
+        const bool early = GP_HEAVY && GP_HEAVY_USE && uni(ctl->tau_early) > 0.0 && !uni(ctl->heavy_ovf);
+        double tau = early ? uni(ctl->tau_early) : 0.0;
+        if (early) {
+            if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
+            GP_SYNC();
+        } else {
+            // Histogram of the segment's records by binade and the top 4 mantissa bits: 64 x 16 counters at the start
+            // of the (idle) table region, indexed so that a larger value has a smaller index.  Records are <= 1, so
+            // binade b = 1023 - biased exponent holds [2^-b, 2^-b+1); the last binade also takes everything smaller and
+            // then gives no threshold.  tau = the lower edge of the counter holding the K-th largest record: within
+            // 6 % of it (the binade counters alone gave up to a factor 2, which claimed ~1.4x the nodes).
+            u32* fine = hist;
+            for (u32 i = tid; i < 1024u; i += BLOCK) fine[i] = 0;
+            if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
+            GP_SYNC();
+            for (u32 base = 0; base < seg_len; base += 8 * BLOCK) {              // 8 loads in flight per thread
+                double vv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const u32 i = base + (u32)u * BLOCK + tid;
-                vv[u] = i < seg_len ? log_val[seg_begin + i] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (vv[u] > 0.0) {
-                    const u64 bits = (u64)__double_as_longlong(vv[u]);
-                    const int e = 1023 - (int)(bits >> 52);
-                    const u32 m4 = (u32)(bits >> 48) & 15u;
-                    const u32 idx = e < 0 ? 15u : e > 63 ? 1023u : (u32)e * 16u + (15u - m4);   // out of range: the lowest counter of the end binade
-                    __hip_atomic_fetch_add(&fine[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int u = 0; u < 8; ++u) {
+                    const u32 i = base + (u32)u * BLOCK + tid;
+                    vv[u] = i < seg_len ? log_val[seg_begin + i] : 0.0;
                 }
-        }
-        GP_SYNC();
-        if (wave == 0) {
-            u32 c[16], sum = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { c[j] = fine[16 * lane + j]; sum += c[j]; }
-            const u32 incl = wave_incl_scan(sum, lane);                      // records >= 2^-lane
-            const u64 m = __ballot(incl >= K);
-            const u32 need = K - (incl - sum);                               // how many of this binade's records are still wanted
-            u32 acc = 0, jsel = 15; bool found = false;
+                for (int u = 0; u < 8; ++u)
+                    if (vv[u] > 0.0) {
+                        const u64 bits = (u64)__double_as_longlong(vv[u]);
+                        const int e = 1023 - (int)(bits >> 52);
+                        const u32 m4 = (u32)(bits >> 48) & 15u;
+                        const u32 idx = e < 0 ? 15u : e > 63 ? 1023u : (u32)e * 16u + (15u - m4);   // out of range: the lowest counter of the end binade
+                        __hip_atomic_fetch_add(&fine[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+            }
+            GP_SYNC();
+            if (wave == 0) {
+                u32 c[16], sum = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { acc += c[j]; if (!found && acc >= need) { jsel = (u32)j; found = true; } }
-            if (m == 0) { if (lane == 0) ctl->tk_bin = 0xFFFFFFFFu; }
-            else if (lane == __ffsll((long long)m) - 1) ctl->tk_bin = 16u * (u32)lane + jsel;
+                for (int j = 0; j < 16; ++j) { c[j] = fine[16 * lane + j]; sum += c[j]; }
+                const u32 incl = wave_incl_scan(sum, lane);                      // records >= 2^-lane
+                const u64 m = __ballot(incl >= K);
+                const u32 need = K - (incl - sum);                               // how many of this binade's records are still wanted
+                u32 acc = 0, jsel = 15; bool found = false;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { acc += c[j]; if (!found && acc >= need) { jsel = (u32)j; found = true; } }
+                if (m == 0) { if (lane == 0) ctl->tk_bin = 0xFFFFFFFFu; }
+                else if (lane == __ffsll((long long)m) - 1) ctl->tk_bin = 16u * (u32)lane + jsel;
+            }
+            GP_SYNC();
+            const u32 fsel = ctl->tk_bin;
+            GP_SYNC();
+            const u32 binade = fsel == 0xFFFFFFFFu ? 63u : fsel >> 4;
+            const u32 bin = binade >= 63u ? 0u : 1023u - binade;                 // biased exponent of tau; 0 = no threshold
+            if (bin != 0xFFFFFFFFu && bin != 0)
+                tau = __longlong_as_double((long long)(((u64)bin << 52) | ((u64)(15u - (fsel & 15u)) << 48)));
+
         }
-        GP_SYNC();
-        const u32 fsel = ctl->tk_bin;
-        GP_SYNC();
-        const u32 binade = fsel == 0xFFFFFFFFu ? 63u : fsel >> 4;
-        const u32 bin = binade >= 63u ? 0u : 1023u - binade;                 // biased exponent of tau; 0 = no threshold
-        if (bin != 0xFFFFFFFFu && bin != 0) {
-            const double tau = __longlong_as_double((long long)(((u64)bin << 52) | ((u64)(15u - (fsel & 15u)) << 48)));
+        if (tau > 0.0) {
             const double thr = tau / (double)n_levels * 0.99999;
             for (u32 i = tid; i < CA; i += BLOCK) { akeys[i] = kEmpty; avals[i] = 0.0; }
             GP_SYNC();
@@ -1472,9 +1522,16 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
                 if (k != kEmpty) ok &= lds_claim(akeys, CA, k);
                 nst = 0;
             };
-            for (u32 base = 0; base < n_log; base += UA * BLOCK) {
+            // (early: the records from heavy_from on were screened as SCAN wrote them -- their qualifying keys are the heavy list)
+            const u32 nA = early ? min(uni(ctl->heavy_from), n_log) : n_log;
+            if (early) {
+                const int* heavy = (const int*)cand;
+                const u32 nh = uni(ctl->n_heavy);
+                for (u32 i = tid; i < nh; i += BLOCK) ok &= lds_claim(akeys, CA, heavy[i]);
+            }
+            for (u32 base = 0; base < nA; base += UA * BLOCK) {
                 int kk[UA]; double vv[UA];
-                load_log_records<BLOCK, UA / 4>(log_key, log_val, base, n_log, tid, kk, vv);   // keys too: one latency, not two
+                load_log_records<BLOCK, UA / 4>(log_key, log_val, base, nA, tid, kk, vv);   // keys too: one latency, not two
 #pragma unroll
                 for (int u = 0; u < UA; ++u) {
                     const bool q = vv[u] >= thr;
@@ -1872,6 +1929,7 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
     }
     // ---- SCAN over the claimed slots
     const u32 lb = uni(ctl->log_count);
+    const Heavy hv = heavy_view(p, ctl);
     u32 st_push = 0, st_edges = 0, st_deg = 0;
     for (u32 j = 0; j < n_list; j += 64u) {
         const bool valid = j + lane < n_list;
@@ -1881,7 +1939,7 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
             k = lkeys[sl]; r = lvals[sl];
             lkeys[sl] = kEmpty; lvals[sl] = 0.0;
             const u32 li = lb + j + lane;                                   // graph.h:90 / :109
-            if ((u64)li < p.log_cap) { w.log_key[li] = k; w.log_val[li] = c * r; } else ctl->fail = 1;
+            if ((u64)li < p.log_cap) { w.log_key[li] = k; w.log_val[li] = c * r; heavy_note(ctl, hv, k, c * r); } else ctl->fail = 1;
         }
         if (!do_push) continue;
         const u32 dq = (u32)k >> p.deg_shift;
@@ -1903,7 +1961,7 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
     }
     st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
     if (lane == 0) {
-        ctl->log_count = lb + n_list;
+        ctl->log_count = lb + n_list; nx->n_rec = n_list;
         if (n_list) stat_add(ctl, sFront, n_list);
         if (st_deg) stat_add(ctl, sDeg, st_deg);
         if (st_push) { stat_add(ctl, sPush, st_push); stat_add(ctl, sEdges, st_edges); }
@@ -2027,6 +2085,63 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
     return 1u;
 }
 
+// The TOP-K threshold, as soon as a level holds >= 2K reserve records (its K-th largest record bounds the K-th largest
+// total from below, see topk_row step 0).  Histogram by binade x top 4 mantissa bits in the 1 024 words of the EXPAND
+// flag areas (idle between a level's SCAN and the next EXPAND); every thread of the workgroup calls this.
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_tau(u32 lds0, u32 seg_begin, u32 seg_len, u32 n_levels_max)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); seg_begin = uni(seg_begin); seg_len = uni(seg_len); n_levels_max = uni(n_levels_max);
+    const WgView w = wg_view(p, lds0);
+    Ctl* ctl = w.ctl;
+    const int tid = threadIdx.x, lane = tid & 63;
+    static_assert(16 * 64 * kFlatW >= 1024 * 4, "the fine histogram lives in the EXPAND flag areas");
+    u32* fine = (u32*)((unsigned char*)ctl + kCtlStruct);
+    const u32 K = (u32)p.K;
+    for (u32 i = tid; i < 1024u; i += BLOCK) fine[i] = 0;
+    GP_SYNC();
+    for (u32 base = 0; base < seg_len; base += 4 * BLOCK) {
+        double vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 i = base + (u32)u * BLOCK + tid;
+            vv[u] = i < seg_len ? w.log_val[seg_begin + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (vv[u] > 0.0) {
+                const u64 bits = (u64)__double_as_longlong(vv[u]);
+                const int e = 1023 - (int)(bits >> 52);
+                const u32 m4 = (u32)(bits >> 48) & 15u;
+                const u32 idx = e < 0 ? 15u : e > 63 ? 1023u : (u32)e * 16u + (15u - m4);
+                __hip_atomic_fetch_add(&fine[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    }
+    GP_SYNC();
+    if (wave_id() == 0) {
+        u32 c[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { c[j] = fine[16 * lane + j]; sum += c[j]; }
+        const u32 incl = wave_incl_scan(sum, lane);                      // records >= 2^-lane
+        const u64 m = __ballot(incl >= K);
+        const u32 need = K - (incl - sum);
+        u32 acc = 0, jsel = 15; bool found = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc += c[j]; if (!found && acc >= need) { jsel = (u32)j; found = true; } }
+        const int bl = m ? __ffsll((long long)m) - 1 : 63;
+        if (lane == bl) {
+            ctl->heavy_from = seg_begin + seg_len; ctl->n_heavy = 0;   // (the level loop calls this for the level that has just ended)
+            if (m != 0 && bl < 63) {
+                const double tau = __longlong_as_double((long long)(((u64)(1023u - (u32)bl) << 52) | ((u64)(15u - jsel) << 48)));
+                ctl->tau_early = tau;
+                ctl->thr_early = tau / (double)n_levels_max * 0.99999;   // <= tau / (levels the row ends up with)
+            }
+        }
+    }
+    GP_SYNC();
+}
+
 template <int BLOCK>
 __device__ GP_PHASE_NOINLINE void phase_topk(u32 lds0, u32 row_lo, u32 row_hi, int seed, u32 seg_begin, u32 seg_len, int n_levels GP_SUB_PARAMS)
 {
@@ -2092,6 +2207,7 @@ __device__ __forceinline__ void gfpush_rows()
             ctl->log_count = 1;                         // record 0 is the seed's own (level 0, written below)
             ctl->n_cand = 0; ctl->fail = 0; ctl->ovf = 0;
             ctl->n_sel = 0; ctl->n_bucket = 0;
+            ctl->thr_early = __builtin_inf(); ctl->tau_early = 0.0; ctl->n_heavy = 0; ctl->heavy_from = 0; ctl->heavy_ovf = 0;
         }
         GP_SYNC();
         const long long qpos = uni(ctl->row);
@@ -2126,7 +2242,8 @@ __device__ __forceinline__ void gfpush_rows()
 #endif
         // state of the level about to be produced: its push list (built by the previous SCAN)
         u32 n_ent_cur = 0, e_cur = 0;
-        u32 seg_begin = 0, seg_len = 0; int n_levels = 0;     // biggest level of the reserve log (coef > 0)
+        u32 seg_begin = 0, seg_len = 0; int n_levels = 0;     // the first level with >= 2K reserve records (coef > 0), else the biggest so far
+        u32 log_pos = 1;                                      // reserve-log records of the levels completed so far (record 0: level 0)
         double dang_cur = 0.0;
         bool has_dang_cur = false;
         int cur = 0;
@@ -2158,7 +2275,7 @@ __device__ __forceinline__ void gfpush_rows()
                         seedrow = p.rows_distinct && !p.force_global && !(kDirectOk<BLOCK> && p.direct) &&
                                   seed_deg <= (u32)(BLOCK / 64) * seedrow_slice<BLOCK>(C);
                         if (seedrow) {                       // level 1 needs neither the entry nor a table; its SCAN starts right behind this
-                            if (tid == 0) { LevelCtr* n1 = &ctl->lc[1]; n1->dangling = 0.0; n1->n_dangling = 0; n1->alloc = 0ull; }   // block's barrier
+                            if (tid == 0) { LevelCtr* n1 = &ctl->lc[1]; n1->dangling = 0.0; n1->n_dangling = 0; n1->n_rec = 0; n1->alloc = 0ull; }   // block's barrier
                         } else
                         if (tid == 0) {
                             if (p.push_cap > 0) { PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push_nxt0[0] = pe; }
@@ -2226,7 +2343,7 @@ __device__ __forceinline__ void gfpush_rows()
                 }
 #endif
             }
-            const u32 snap_log = uni(ctl->log_count);          // first log record of this level
+            const u32 snap_log = log_pos;                      // first log record of this level
 #ifdef GP_DIAG
             const u64 lv_e0 = tk_expand, lv_s0 = tk_scan; u32 lv_passes = 0;
 #endif
@@ -2236,7 +2353,7 @@ __device__ __forceinline__ void gfpush_rows()
             LevelCtr* nx = &ctl->lc[lvl & 1];
             const bool lvl_seedrow = lvl == 1 && seedrow;      // (its counters were cleared in front of level 0's barrier)
             if (tid == 0 && !lvl_seedrow) {
-                nx->dangling = 0.0; nx->n_dangling = 0; nx->alloc = 0ull;
+                nx->dangling = 0.0; nx->n_dangling = 0; nx->n_rec = 0; nx->alloc = 0ull;
             }
             if (!in_lds) {
                 parts = 1;
@@ -2340,14 +2457,20 @@ __device__ __forceinline__ void gfpush_rows()
             if (tid == 0) {            // (in LDS: a global atomic here would be awaited at the next phase call's entry)
                 u64* dx = ctl->lvl_acc[min(lvl, 15)];
                 dx[0] += tk_expand - lv_e0; dx[1] += tk_scan - lv_s0; dx[2] += (u64)e_cur;
-                dx[3] += (u64)(ctl->log_count - snap_log); dx[4] += (u64)n_ent_cur; dx[5] += (u64)lv_passes;
+                dx[3] += (u64)nx->n_rec; dx[4] += (u64)n_ent_cur; dx[5] += (u64)lv_passes;
             }
 #endif
             {
-                const u32 lvl_len = uni(ctl->log_count) - snap_log;      // read after the level's last barrier
+                const u32 lvl_len = uni(nx->n_rec);                      // read after the level's last barrier (see LevelCtr::n_rec)
+                log_pos += lvl_len;
                 n_levels = lvl + 1;
                 // first level with >= 2K records (early levels hold the LARGEST records: a stronger bound than the biggest level)
-                if (c > 0.0 && seg_len < 2u * (u32)p.K && lvl_len > seg_len) { seg_begin = snap_log; seg_len = lvl_len; }
+                if (c > 0.0 && seg_len < 2u * (u32)p.K && lvl_len > seg_len) {
+                    seg_begin = snap_log; seg_len = lvl_len;
+#if GP_HEAVY
+                    if (seg_len >= 2u * (u32)p.K && p.prune && do_push && !uni(ctl->fail)) phase_tau<BLOCK>(lds0, seg_begin, seg_len, (u32)(L + 1));
+#endif
+                }
             }
             if (!do_push || uni(ctl->fail)) break;
             { const u64 al = uni(nx->alloc); n_ent_cur = (u32)al; e_cur = (u32)(al >> 32); }

@@ -9,6 +9,6 @@ for w in $W; do
   r=$ROWS; [ $w = amazon2m ] && r=12350
   for rep in 1 2; do for pr in "${PAIRS[@]}"; do
     lib=${pr%%|*}; opts=${pr#*|}
-    GRANDPLUS_LIB=$lib python bench.py --workload $w --seeds-per-gpu $r --steps $STEPS --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows $opts 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$w $lib [$opts]', round(d['value']), d['roofline']['kernel_ms_avg'])"
+    GRANDPLUS_LIB=$lib timeout 300 python bench.py --workload $w --seeds-per-gpu $r --steps $STEPS --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows $opts 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$w $lib [$opts]', round(d['value']), d['roofline']['kernel_ms_avg'])"
   done; done
 done

@@ -94,6 +94,9 @@ constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic
 #endif
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (edge_stream)
 constexpr int    kThreeLds   = 53248;   // dynamic LDS of a workgroup when three share a CU (160 KB / 3, allocation granularity)
+#ifndef GP_TOPK_UF
+#define GP_TOPK_UF 12
+#endif
 #ifndef GP_HEAVY_USE
 #define GP_HEAVY_USE 1
 #endif
@@ -1597,17 +1600,13 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
             GP_SYNC();
             GP_SUB(0); GP_SUB_COUNT(8, 1);
             bool ok = true;
-            for (u32 base = 0; base < n_log && ok; base += 4 * BLOCK) {
+            constexpr int UF = GP_TOPK_UF;            // records in flight per thread: 12 with 9 wide loads (was 4 with 8: a pass is cold streaming reads)
+            for (u32 base = 0; base < n_log && ok; base += UF * BLOCK) {
                 if (ctl->ovf) break;                 // some other thread already gave up on this pass
-                int kk[4]; double vv[4];
+                int kk[UF]; double vv[UF];
+                load_log_records<BLOCK, UF / 4>(log_key, log_val, base, n_log, tid, kk, vv);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const u32 i = base + (u32)u * BLOCK + tid;
-                    kk[u] = kEmpty; vv[u] = 0.0;
-                    if (i < n_log) { kk[u] = log_key[i]; vv[u] = log_val[i]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < UF; ++u)
                     if (kk[u] != kEmpty && (parts == 1 || slot_of(hash_b((u32)kk[u]), parts) == part))
                         ok &= res_add_lds(akeys, avals, CA, kk[u], vv[u]);
             }

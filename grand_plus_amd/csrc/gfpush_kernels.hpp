@@ -128,7 +128,7 @@ constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts w
 #define GP_SOLO 1
 #endif
 #ifndef GP_BUCKET_MIN
-#define GP_BUCKET_MIN 3
+#define GP_BUCKET_MIN 4            // (3 until three workgroups shared a CU: at 52 KB three partition passes beat the buckets, MAG +1.8 %, Reddit +2.8 %)
 #endif
 constexpr u32    kBucketMin  = GP_BUCKET_MIN;       // levels needing at least this many partitions bucket their edges in HBM once
                                         // instead of re-reading and hash-filtering every CSR range once per partition

@@ -2193,6 +2193,12 @@ __device__ __forceinline__ void gfpush_rows()
     const u64 wave_t0 = clock64();
 #endif
     const int L = p.n_coef - 1;
+    // A one-wave level must not be able to hit a workspace bound: wave 0 runs ahead of the other waves there, and a failure
+    // flag raised by it could be seen by a wave that is still finishing the level before (it would leave the level loop alone).
+    // Its records (<= kSoloEdges + 1) and entries are checked against the capacities up front, and the boundary table must hold
+    // the largest level any frontier can produce (degrees pushed in one level sum to <= 1/rmax).
+    const double solo_e_bound = p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz;
+    const bool solo_caps = p.push_cap >= (u64)kSoloEdges + 4u && (double)p.bt_cap >= solo_e_bound / (double)(1u << kUnitShift) + 4.0;
 
     for (;;) {
 #ifdef GP_DIAG
@@ -2356,9 +2362,11 @@ __device__ __forceinline__ void gfpush_rows()
             }
             if (!in_lds) {
                 parts = 1;
-                if (2 * need > p.resg_cap) { if (tid == 0) ctl->fail = 1; }
+                const bool too_big = 2 * need > p.resg_cap;               // (wave-uniform)
                 cap = (u32)min(p.resg_cap, max((u64)kMinCap, 2 * need));
                 GP_SYNC();
+                // raised behind the barrier, and seen by everyone behind the next: a wave may still have been reading the flag for the level before
+                if (too_big) { if (tid == 0) ctl->fail = 1; GP_SYNC(); }
             }
             // Hash partitions (q, P) of the level's targets, refined in place on overflow exactly
             // like the aggregation partitions of topk_row (nothing to undo: a partition is
@@ -2379,7 +2387,8 @@ __device__ __forceinline__ void gfpush_rows()
             // a small level: one wave does it, the others park at one barrier (phase_solo_level)
             bool solo_done = false;
             if (GP_SOLO && in_lds && !direct && parts == 1 && !lvl_seedrow && !use_buckets && p.solo &&
-                e_cur <= kSoloEdges && n_ent_cur >= 1u && n_ent_cur <= kSoloEntries && !uni(ctl->fail)) {
+                e_cur <= kSoloEdges && n_ent_cur >= 1u && n_ent_cur <= kSoloEntries && !uni(ctl->fail) &&
+                solo_caps && (u64)log_pos + kSoloEdges + 2u <= p.log_cap) {
                 GP_STAMP(t0);
                 if (wave_id() == 0)
                     phase_solo_level<BLOCK>(lds0, (u32)lvl, (u32)cur, n_ent_cur, e_cur, has_dang_cur ? 1u : 0u, dang_cur, seed_key, c, do_push ? 1u : 0u);

@@ -317,19 +317,26 @@ def run_rank(args) -> int:
             torch.cuda.synchronize(dev)
 
     # Settling, before the W warmup steps and outside every clock: on a freshly started GPU box the first tens of seconds can
-    # run several times slower than the steady state (observed on this pool: whole bench processes at 120-160 ms per MAG
-    # launch, the next one at 27 ms).  Repeat the first warmup batch until two consecutive launches agree within 10 % and
-    # with the fastest seen so far within 15 %; at most 12 launches or 20 s.  The count is reported as `settle_steps`.
-    settle_steps = 0
+    # run several times slower than the steady state (observed on this pool: the first bench process of a box at 120-160 ms
+    # per MAG launch -- 4.8x, the ratio of the 2.4 GHz peak to the 500 MHz idle shader clock -- and 27 ms later in the same
+    # process).  Repeat the first warmup batch until two consecutive launches agree within 10 %, agree with the fastest seen
+    # so far within 15 %, and the shader clock measured on the device (gp_internal_clock_mhz: one wave counting its cycles
+    # over 200 us of the constant 100 MHz clock) has reached 80 % of its maximum; at most 60 launches or 60 s.  The count and
+    # the last clock reading are reported as `settle_steps` / `settle_clock_mhz`.
+    settle_steps = 0; settle_mhz = None
     if not args.no_settle:
+        from grand_plus_amd import _native
+        max_mhz = float(getattr(torch.cuda.get_device_properties(dev), "clock_rate", 0)) / 1000.0      # kHz -> MHz (0: unknown, no clock criterion)
         seen = []
         t_settle = time.perf_counter()
-        while settle_steps < 12:
+        while settle_steps < 60:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); step(0); b.record(); torch.cuda.synchronize(dev)
             seen.append(a.elapsed_time(b)); settle_steps += 1
-            ok = len(seen) >= 2 and abs(seen[-1] - seen[-2]) <= 0.10 * seen[-1] and seen[-1] <= 1.15 * min(seen)
-            late = time.perf_counter() - t_settle >= 20.0
+            settle_mhz = _native.shader_clock_mhz(local_rank)
+            ok = (len(seen) >= 2 and abs(seen[-1] - seen[-2]) <= 0.10 * seen[-1] and seen[-1] <= 1.15 * min(seen)
+                  and (max_mhz <= 0 or settle_mhz >= 0.8 * max_mhz))
+            late = time.perf_counter() - t_settle >= 60.0
             if world > 1:                       # every rank leaves the loop in the same iteration (step() holds a collective)
                 flag = torch.tensor([1 if ok else 0, 0 if late else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -376,7 +383,7 @@ def run_rank(args) -> int:
         sha = kernel_source_sha16()
         line = {
             "metric": "propagation-matrix rows/sec (whole node)", "value": round(value, 1), "unit": "rows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps, "settle_clock_mhz": None if settle_mhz is None else round(settle_mhz),
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if source.startswith("synth:") else "fixture graph (tests/golden), seeds cycled",

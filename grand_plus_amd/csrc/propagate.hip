@@ -201,6 +201,16 @@ bool hip_ok(hipError_t e, const char* what) {
 
 }  // namespace
 
+// Measurement aid (bench.py): the shader clock the GPU is running at right now.  One wave spins for ~200 us of the constant
+// 100 MHz wall clock and reports how many shader cycles (s_memtime) went by.
+__global__ void clock_probe_kernel(unsigned long long* out) {
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < 20000ull) w1 = wall_clock64();
+    const unsigned long long c1 = clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+
 extern "C" {
 
 int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim, const float* d_edge_weight,
@@ -289,6 +299,20 @@ int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim
     if (mode == 2) { if (!hip_ok(hipMemcpyAsync(d_out, cur, nf * sizeof(float), hipMemcpyDeviceToDevice, s), "hipMemcpyAsync")) return GP_ERR_HIP; }
     if (!hip_ok(hipGetLastError(), "propagate kernels")) return GP_ERR_HIP;
     return GP_OK;                                          // ~Scratch frees
+}
+
+int gp_internal_clock_mhz(int device, double* shader_mhz) {
+    if (!shader_mhz) return GP_ERR_NULL;
+    *shader_mhz = 0.0;
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return GP_ERR_HIP;
+    unsigned long long* d = nullptr; unsigned long long h[2] = {0, 0};
+    if (!hip_ok(hipMalloc(&d, sizeof h), "hipMalloc")) return GP_ERR_HIP;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, 0, d);
+    const bool ok = hip_ok(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost), "hipMemcpy");
+    (void)hipFree(d);
+    if (!ok) return GP_ERR_HIP;
+    if (h[1]) *shader_mhz = 100.0 * (double)h[0] / (double)h[1];
+    return GP_OK;
 }
 
 }  // extern "C"

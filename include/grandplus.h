@@ -238,6 +238,9 @@ int gp_internal_multi_plan(int64_t n_seeds, int K, int n_parts, int64_t min_rows
 
 /* internal: lets the second translation unit report through gp_last_error (not for callers) */
 void gp_internal_set_error(int status, const char* where, const char* detail);
+/* Measurement aid (bench.py, not part of the reference's interface): the shader clock `device` runs at right now, in MHz --
+ * shader cycles counted by one wave over ~200 us of the constant 100 MHz clock. */
+int gp_internal_clock_mhz(int device, double* shader_mhz);
 
 #ifdef __cplusplus
 }

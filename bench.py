@@ -321,7 +321,7 @@ def run_rank(args) -> int:
     # per MAG launch -- 4.8x, the ratio of the 2.4 GHz peak to the 500 MHz idle shader clock -- and 27 ms later in the same
     # process).  Repeat the first warmup batch until two consecutive launches agree within 10 %, agree with the fastest seen
     # so far within 15 %, and the shader clock measured on the device (gp_internal_clock_mhz: one wave counting its cycles
-    # over 200 us of the constant 100 MHz clock) has reached 80 % of its maximum; at most 60 launches or 60 s.  The count and
+    # over 200 us of the constant 100 MHz clock) has reached 80 % of its maximum; at most 40 launches or 45 s.  The count and
     # the last clock reading are reported as `settle_steps` / `settle_clock_mhz`.
     settle_steps = 0; settle_mhz = None
     if not args.no_settle:
@@ -329,14 +329,14 @@ def run_rank(args) -> int:
         max_mhz = float(getattr(torch.cuda.get_device_properties(dev), "clock_rate", 0)) / 1000.0      # kHz -> MHz (0: unknown, no clock criterion)
         seen = []
         t_settle = time.perf_counter()
-        while settle_steps < 60:
+        while settle_steps < 40:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); step(0); b.record(); torch.cuda.synchronize(dev)
             seen.append(a.elapsed_time(b)); settle_steps += 1
             settle_mhz = _native.shader_clock_mhz(local_rank)
             ok = (len(seen) >= 2 and abs(seen[-1] - seen[-2]) <= 0.10 * seen[-1] and seen[-1] <= 1.15 * min(seen)
                   and (max_mhz <= 0 or settle_mhz >= 0.8 * max_mhz))
-            late = time.perf_counter() - t_settle >= 60.0
+            late = time.perf_counter() - t_settle >= 45.0
             if world > 1:                       # every rank leaves the loop in the same iteration (step() holds a collective)
                 flag = torch.tensor([1 if ok else 0, 0 if late else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -318,24 +318,26 @@ def run_rank(args) -> int:
 
     # Settling, before the W warmup steps and outside every clock: on a freshly started GPU box the first tens of seconds can
     # run several times slower than the steady state (observed on this pool: the first bench process of a box at 120-160 ms
-    # per MAG launch -- 4.8x, the ratio of the 2.4 GHz peak to the 500 MHz idle shader clock -- and 27 ms later in the same
-    # process).  Repeat the first warmup batch until two consecutive launches agree within 10 %, agree with the fastest seen
-    # so far within 15 %, and the shader clock measured on the device (gp_internal_clock_mhz: one wave counting its cycles
-    # over 200 us of the constant 100 MHz clock) has reached 80 % of its maximum; at most 40 launches or 45 s.  The count and
-    # the last clock reading are reported as `settle_steps` / `settle_clock_mhz`.
-    settle_steps = 0; settle_mhz = None
+    # per MAG launch, 4.8x, and 27 ms later in the same process; the launches of such a phase agree with each other).  Repeat
+    # the first warmup batch until two consecutive launches agree within 10 %, agree with the fastest seen so far within
+    # 15 %, and the device delivers what an MI355X delivers in the steady state on two probes that do not depend on any
+    # counter's time base (gp_internal_speed_probe): a dependent integer multiply-add chain in one wave (60.9 iterations per
+    # microsecond at 2.4 GHz: proportional to the shader clock) and a 256 MiB streaming copy (5.1-5.6 TB/s read + write);
+    # at most 40 launches or 45 s.  Count and last readings are reported as `settle_steps` / `settle_probe`.
+    settle_steps = 0; settle_probe = None
     if not args.no_settle:
         from grand_plus_amd import _native
-        max_mhz = float(getattr(torch.cuda.get_device_properties(dev), "clock_rate", 0)) / 1000.0      # kHz -> MHz (0: unknown, no clock criterion)
+        ALU_REF, COPY_REF = 60.9, 5300.0                  # tools/clock_timeline.py on a settled MI355X box (gpurun_out/clk2.txt)
         seen = []
         t_settle = time.perf_counter()
         while settle_steps < 40:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); step(0); b.record(); torch.cuda.synchronize(dev)
             seen.append(a.elapsed_time(b)); settle_steps += 1
-            settle_mhz = _native.shader_clock_mhz(local_rank)
+            alu, gbs = _native.speed_probe(local_rank)
+            settle_probe = {"alu_iters_per_us": round(alu, 1), "copy_gb_s": round(gbs), "shader_clock_mhz": round(_native.shader_clock_mhz(local_rank))}
             ok = (len(seen) >= 2 and abs(seen[-1] - seen[-2]) <= 0.10 * seen[-1] and seen[-1] <= 1.15 * min(seen)
-                  and (max_mhz <= 0 or settle_mhz >= 0.8 * max_mhz))
+                  and alu >= 0.75 * ALU_REF and gbs >= 0.6 * COPY_REF)
             late = time.perf_counter() - t_settle >= 45.0
             if world > 1:                       # every rank leaves the loop in the same iteration (step() holds a collective)
                 flag = torch.tensor([1 if ok else 0, 0 if late else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
@@ -383,7 +385,7 @@ def run_rank(args) -> int:
         sha = kernel_source_sha16()
         line = {
             "metric": "propagation-matrix rows/sec (whole node)", "value": round(value, 1), "unit": "rows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps, "settle_clock_mhz": None if settle_mhz is None else round(settle_mhz),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps, "settle_probe": settle_probe,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if source.startswith("synth:") else "fixture graph (tests/golden), seeds cycled",

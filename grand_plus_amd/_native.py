@@ -27,7 +27,7 @@ EXPORTS = (
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
-    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_clock_mhz",
+    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_clock_mhz", "gp_internal_speed_probe",
 )
 
 
@@ -119,6 +119,8 @@ def lib():
     L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    L.gp_internal_speed_probe.restype = ctypes.c_int
+    L.gp_internal_speed_probe.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.gp_internal_clock_mhz.restype = ctypes.c_int
     L.gp_internal_clock_mhz.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     if L.gp_abi_version() != 2:
@@ -145,3 +147,10 @@ def shader_clock_mhz(device: int = 0) -> float:
     mhz = ctypes.c_double(0.0)
     raise_for_status(lib().gp_internal_clock_mhz(int(device), ctypes.byref(mhz)))
     return float(mhz.value)
+
+
+def speed_probe(device: int = 0):
+    """(ALU iterations per us of a dependent multiply-add chain in one wave, GB/s of a 256 MiB streaming copy) on `device`."""
+    alu, gbs = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    raise_for_status(lib().gp_internal_speed_probe(int(device), ctypes.byref(alu), ctypes.byref(gbs)))
+    return float(alu.value), float(gbs.value)

@@ -241,6 +241,10 @@ void gp_internal_set_error(int status, const char* where, const char* detail);
 /* Measurement aid (bench.py, not part of the reference's interface): the shader clock `device` runs at right now, in MHz --
  * shader cycles counted by one wave over ~200 us of the constant 100 MHz clock. */
 int gp_internal_clock_mhz(int device, double* shader_mhz);
+/* Measurement aid: what `device` delivers right now, independent of any counter's time base -- iterations per microsecond of a
+ * dependent integer multiply-add chain in one wave (proportional to the shader clock) and GB/s (read + write) of a 256 MiB
+ * streaming copy over the whole chip. */
+int gp_internal_speed_probe(int device, double* alu_iters_per_us, double* copy_gb_s);
 
 #ifdef __cplusplus
 }

@@ -16,5 +16,6 @@ t0 = time.time()
 while time.time() - t0 < float(sys.argv[1]):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); g.gfpush_device(seeds, r.coef(), r.rmax, r.top_k); b.record(); torch.cuda.synchronize()
-    print(round(time.time()-t00,1), 'ms', round(a.elapsed_time(b),2), 'mhz', round(_native.shader_clock_mhz(0)), flush=True)
+    alu, gbs = _native.speed_probe(0)
+    print(round(time.time()-t00,1), 'ms', round(a.elapsed_time(b),2), 'mhz', round(_native.shader_clock_mhz(0)), 'alu_iters_per_us', round(alu,1), 'copy_gb_s', round(gbs), flush=True)
     time.sleep(float(sys.argv[2]))

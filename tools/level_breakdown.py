@@ -43,8 +43,8 @@ def main():
         names = ["agg_init", "agg_insert", "agg_scan", "sel_hist", "sel_pick", "sel_compact", "sel_collect", "final"]
         print("   topk sub-phases (us/row):", {n: round(st["diag_sub"][i] / rows / 100, 2) for i, n in enumerate(names)}, flush=True)
         if len(st["diag_sub"]) >= 13:
-            print("   topk counts per row: full-aggregation table passes %.3f  select histogram passes over HBM %.3f / over LDS %.3f  rows finished by the pruned path %.3f (its partitions, summed %.3f)"
-                  % tuple(st["diag_sub"][i] / rows for i in (8, 9, 10, 11, 12)), flush=True)
+            print("   topk counts per row: full-aggregation table passes %.3f  select histogram passes over HBM %.3f / over LDS %.3f  rows finished by the pruned path %.3f"
+                  % tuple(st["diag_sub"][i] / rows for i in (8, 9, 10, 11)), flush=True)
         if os.environ.get("GP_SITES"):
             # barrier sites in source order: GP_SYNC() occurrences after the macro definitions
             src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "grand_plus_amd", "csrc", "gfpush_kernels.hpp")).read().split("\n")

@@ -530,6 +530,25 @@ def test_lds_budget_too_small_for_topk_is_rejected():
     _assert_parity(seeds, K, (row, col, val), exp)
 
 
+def test_launch_shape_follows_the_recipe():
+    """DESIGN.md section 3, launch shape: three 512-thread workgroups per CU (52 KB of LDS each) for rmax >= 5e-6 and K <= 128, two
+    768-thread workgroups (80 KB) for 128 < K <= 256, one 1024-thread workgroup owning all 160 KB for a small rmax on a graph that
+    is neither tiny nor sparse.  Whatever the shape, the rows are the oracle's."""
+    import torch
+    from grand_plus_amd import synth
+    indptr, indices = synth.shape_csr("small")                      # 100 k nodes, nnz / N = 14: neither tiny nor sparse
+    seeds = synth.seeds(len(indptr) - 1, 2048)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    coef = np.array([0.4, 0.3, 0.2, 0.1])
+    for rmax, K, threads, lds, per_cu in ((1e-5, 32, 512, 53248, 3), (1e-5, 200, 768, 81920, 2), (1e-6, 32, 1024, 163840, 1)):
+        got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K)
+        assert (st["block_threads"], st["lds_bytes"]) == (threads, lds), (rmax, K, st["block_threads"], st["lds_bytes"])
+        assert st["workgroups"] == min(per_cu * cus, len(seeds)) and st["failed_rows"] == 0
+        exp, _ = _oracle(indptr, indices, seeds[:256], coef, rmax, K)
+        sub = tuple(a[:256 * K] for a in got)
+        _assert_parity(seeds[:256], K, sub, exp)
+
+
 def test_multi_gpu_handle_one_call_uses_every_gpu():
     """gp_graph_create_multi: seeds block-partitioned over the GPUs inside ONE gfpush_omp call, one
     ncclAllGather of the packed slabs, one D2H.  On a single-GPU box the same path runs with a one-rank

@@ -323,7 +323,8 @@ def run_rank(args) -> int:
     # 15 %, and the device delivers what an MI355X delivers in the steady state on two probes that do not depend on any
     # counter's time base (gp_internal_speed_probe): a dependent integer multiply-add chain in one wave (60.9 iterations per
     # microsecond at 2.4 GHz: proportional to the shader clock) and a 256 MiB streaming copy (5.1-5.6 TB/s read + write);
-    # at most 40 launches or 45 s.  Count and last readings are reported as `settle_steps` / `settle_probe`.
+    # for at most 90 s (the slow phases seen lasted 40-55 s from a process's first launch).  Count and last readings are
+    # reported as `settle_steps` / `settle_probe`.
     settle_steps = 0; settle_probe = None
     if not args.no_settle:
         from grand_plus_amd import _native
@@ -340,7 +341,7 @@ def run_rank(args) -> int:
             ref_ms = None
         seen = []
         t_settle = time.perf_counter()
-        while settle_steps < 40:
+        while settle_steps < 2000:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); step(0); b.record(); torch.cuda.synchronize(dev)
             seen.append(a.elapsed_time(b)); settle_steps += 1
@@ -349,7 +350,7 @@ def run_rank(args) -> int:
                             "launch_ms": round(seen[-1], 3), "profiled_launch_ms": ref_ms}
             ok = (len(seen) >= 2 and abs(seen[-1] - seen[-2]) <= 0.10 * seen[-1] and seen[-1] <= 1.15 * min(seen)
                   and alu >= 0.75 * ALU_REF and gbs >= 0.6 * COPY_REF and (ref_ms is None or seen[-1] <= 1.5 * ref_ms))
-            late = time.perf_counter() - t_settle >= 45.0
+            late = time.perf_counter() - t_settle >= 90.0
             if world > 1:                       # every rank leaves the loop in the same iteration (step() holds a collective)
                 flag = torch.tensor([1 if ok else 0, 0 if late else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -94,6 +94,9 @@ constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic
 #endif
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (edge_stream)
 constexpr int    kThreeLds   = 53248;   // dynamic LDS of a workgroup when three share a CU (160 KB / 3, allocation granularity)
+#ifndef GP_RATIO_EST
+#define GP_RATIO_EST 1
+#endif
 #ifndef GP_TOPK_UF
 #define GP_TOPK_UF 12
 #endif
@@ -187,6 +190,10 @@ struct Ctl {
     u32 heavy_from;       // first reserve-log record covered by the heavy list
     u32 heavy_ovf;        // the list outgrew its buffer: TOP-K sweeps the log as before
     u32 pad_heavy;
+    // Distinct targets per edge of each level, as this workgroup's earlier rows had them (x 1.15 margin, in 1/1024; 0: no row yet;
+    // quick to rise, slow to fall).  The level's table is planned for edges x this instead of for the edge count: on the citation
+    // graphs a level of 6 600 edges reaches 2 100 nodes and fits ONE pass where the edge count asked for three.
+    u32 ratio_q[16];
 #ifdef GP_DIAG
     u64 lvl_acc[16][6];   // per level: expand ticks, scan ticks, edges, frontier nodes, push entries, table passes (flushed once per workgroup)
     u64 row_acc[4];       // per row: prologue, level 0, level loop outside EXPAND/SCAN, table restore (ticks)
@@ -2175,6 +2182,7 @@ __device__ __forceinline__ void gfpush_rows()
     wipe_table<BLOCK>(lkeys, lvals, C);
     if (tid < (int)(sizeof(ctl->st) / sizeof(ctl->st[0]))) { ctl->st[tid] = 0; ctl->st_row[tid] = 0; }      // visible after the first row's barriers
     if (tid < kCoefLds && tid < p.n_coef) ctl->coef[tid] = p.coef[tid];
+    if (tid < 16) ctl->ratio_q[tid] = 0;
     const long long n_rows = p.n_rows_dev ? (long long)*p.n_rows_dev : p.n_seeds;    // rows in this launch's queue
     u32 max_e = 0, max_log = 0;                                                      // observed maxima of this workgroup
     u64 tk_scan = 0, tk_expand = 0, tk_topk = 0, tk_total = 0, t0 = 0, t1 = 0, t2 = 0, tk_begin = 0;
@@ -2310,6 +2318,14 @@ __device__ __forceinline__ void gfpush_rows()
             const u64 need = min((u64)e_cur + (has_dang_cur ? 1 : 0), (u64)p.n_nodes);
             if (need == 0) break;                       // the frontier died: later levels add nothing
             max_e = max(max_e, e_cur);
+            // what the LDS table is planned for: the estimate of DISTINCT targets (Ctl::ratio_q); a level that outgrows it overflows
+            // its table and is split like any partition that does not fit
+            u64 need_t = need;
+#if GP_RATIO_EST
+            // (only where it changes the plan: at >= 0.8 targets per edge -- the power-law shapes -- the estimate buys no pass and an
+            //  overflow now and then costs one: MAG -0.6 % when it was applied everywhere)
+            if (lvl < 16) { const u32 rq = uni(ctl->ratio_q[lvl]); if (rq && rq <= 820u) need_t = min(need, (((u64)e_cur * rq) >> 10) + 64u); }
+#endif
             // placement of the level's residue table
             bool in_lds = !p.force_global;
             u32 parts = 1, cap = 0;
@@ -2335,14 +2351,14 @@ __device__ __forceinline__ void gfpush_rows()
                     if (parts > kMaxParts) in_lds = false;
                 }
 #else
-                if (need * GP_LOAD_DEN <= (u64)C * GP_LOAD_NUM) {
-                    cap = min(C, max(kMinCap, ((u32)GP_CAP_MULT * (u32)need + 3u) & ~3u));
-                } else if (need > (u64)kMaxParts * C) {
+                if (need_t * GP_LOAD_DEN <= (u64)C * GP_LOAD_NUM) {
+                    cap = min(C, max(kMinCap, ((u32)GP_CAP_MULT * (u32)need_t + 3u) & ~3u));
+                } else if (need_t > (u64)kMaxParts * C) {
                     in_lds = false;                      // more than kMaxParts partitions: the HBM table
                 } else {
                     // target load of a partition: 0.75 of the table counted in EDGES (distinct targets are ~15 % fewer); a partition
                     // that overflows anyway is split in place.  0.55 -> 0.75 saved half a pass on the peak levels of the 80 KB shape (+2 %).
-                    parts = ((u32)need * GP_LOAD_DEN + C * GP_LOAD_NUM - 1u) / (C * GP_LOAD_NUM);       // need <= 64 C < 2^21: 32-bit arithmetic
+                    parts = ((u32)need_t * GP_LOAD_DEN + C * GP_LOAD_NUM - 1u) / (C * GP_LOAD_NUM);     // need_t <= 64 C < 2^21: 32-bit arithmetic
                     cap = C;
                     if (parts > kMaxParts) in_lds = false;
                 }
@@ -2435,6 +2451,7 @@ __device__ __forceinline__ void gfpush_rows()
                             wipe_table<BLOCK>(lkeys, lvals, C);
                             GP_SYNC();
                             if (tid == 0) ctl->ovf = 0;
+                            if (in_lds && !direct) cap = C;      // (a single-pass table sized from the estimate may have been smaller)
                             if (np < 0x20000000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
                             if (tid == 0) ctl->fail = 1;
                             GP_SYNC();
@@ -2471,6 +2488,13 @@ __device__ __forceinline__ void gfpush_rows()
             {
                 const u32 lvl_len = uni(nx->n_rec);                      // read after the level's last barrier (see LevelCtr::n_rec)
                 log_pos += lvl_len;
+#if GP_RATIO_EST
+                if (tid == 0 && lvl < 16 && e_cur > 0u) {                // lvl_len = the level's distinct targets
+                    const u32 obs = min(1024u, (u32)(1178.0f * (float)lvl_len * __frcp_rn((float)e_cur)) + 2u);    // 1.15 x 1024 x nodes / edges, rounded up (fp32: a 64-bit division here is ~150 instructions per level)
+                    const u32 old_q = ctl->ratio_q[lvl];
+                    ctl->ratio_q[lvl] = max(obs, old_q - (old_q >> 3));
+                }
+#endif
                 n_levels = lvl + 1;
                 // first level with >= 2K records (early levels hold the LARGEST records: a stronger bound than the biggest level)
                 if (c > 0.0 && seg_len < 2u * (u32)p.K && lvl_len > seg_len) {

@@ -364,7 +364,7 @@ def run_rank(args) -> int:
     # a timed block now and then runs 4-5x slower than the profiled launch of the same kernel sources although the launches
     # right before it (settling) and after it (host API) run at the profiled speed and neither probe moves (DESIGN.md
     # section 4).  When the block's launches average more than `ref_factor` x the profiled launch, the block (warmup + K
-    # steps) is repeated after a pause, at most twice; every discarded attempt is reported in `discarded_attempts`.
+    # steps) is repeated after a 20 s pause, at most twice; every discarded attempt is reported in `discarded_attempts`.
     discarded = []
     while True:
         for i in range(args.warmup):
@@ -396,7 +396,7 @@ def run_rank(args) -> int:
         discarded.append({"ms_per_step": round(elapsed / args.steps * 1e3, 3), "kernel_ms_avg": round(avg_ms, 3),
                           "library_kernel_ms_last": round(float(stats.get("kernel_ms", 0.0)), 3), "profiled_launch_ms": ref_ms})
         print(f"[bench] rank {rank}: timed block at {avg_ms:.1f} ms per launch against {ref_ms:.1f} ms profiled -- repeating it", file=sys.stderr, flush=True)
-        time.sleep(10.0)
+        time.sleep(20.0)
     per_rank_ms = [round(avg_ms, 3)]
     if world > 1:
         red_dev = dev if backend == "nccl" else "cpu"

@@ -353,6 +353,9 @@ def run_rank(args) -> int:
             tol = 0.10 if world == 1 else 0.25            # (a step of several ranks ends with a collective)
             ok = (len(seen) >= 2 and abs(seen[-1] - seen[-2]) <= tol * seen[-1] and seen[-1] <= (1.05 + tol) * min(seen)
                   and alu >= 0.75 * ALU_REF and gbs >= 0.6 * COPY_REF and (ref_ms is None or world > 1 or seen[-1] <= ref_factor * ref_ms))     # (a step of several ranks ends with the gather: the profiled KERNEL time is compared after the timed block instead)
+            # (the two anomalous blocks seen inside a process began 0.5-1 s after its first launches, behind three fast settling
+            #  launches: settling therefore lasts at least 6 s, so that such a phase begins -- and is waited out -- inside it)
+            ok = ok and time.perf_counter() - t_settle >= 6.0
             late = time.perf_counter() - t_settle >= (90.0 if world == 1 else 30.0)
             if world > 1:                       # every rank leaves the loop in the same iteration (step() holds a collective)
                 flag = torch.tensor([1 if ok else 0, 0 if late else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")

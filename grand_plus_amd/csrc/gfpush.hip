@@ -88,6 +88,7 @@ struct gp_graph {
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
+    int lds_pad = 0; int pretouch = 0;                                    // experiment knobs: extra dynamic LDS per workgroup that the tables do not use (forces fewer workgroups per CU); memset the workspace when it is allocated
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
@@ -243,6 +244,7 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
             return fail(GP_ERR_NOMEM, "hipMalloc(%zu bytes of gfpush workspace): %s", total, hipGetErrorString(e));
         }
         w.bytes = total;
+        if (g->pretouch && hipMemset(w.base, 0, total) != hipSuccess) (void)hipGetLastError();
         char* p = (char*)w.base;
         w.est = est; p += w.est.carve(p, est.n_wg);
         w.big = big; if (big.n_wg > 0) p += w.big.carve(p, big.n_wg);
@@ -527,6 +529,11 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "lds_bytes") {
         if (value < 40 * 1024 || value > 160 * 1024) return fail(GP_ERR_INVALID_ARG, "lds_bytes must be in [40960, 163840]");
         g->lds_bytes = (int)(value & ~15ll);
+    } else if (k == "lds_pad") {
+        if (value < 0 || value > 120 * 1024) return fail(GP_ERR_INVALID_ARG, "lds_pad must be in [0, 122880]");
+        g->lds_pad = (int)(value & ~15ll);       // dynamic LDS the tables do not use: fewer workgroups per CU at the same table size (occupancy experiments)
+    } else if (k == "pretouch") {
+        g->pretouch = value ? 1 : 0;             // memset the whole workspace when it is allocated (slow-phase experiment)
     } else if (k == "max_workgroups") {
         if (value < 0 || value > 65535) return fail(GP_ERR_INVALID_ARG, "max_workgroups must be in [0, 65535]");
         g->max_workgroups = (int)value;
@@ -636,10 +643,10 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
 
         int per_cu = 1;
         switch (block_threads) {
-            case 256: rc = resident_blocks<256>(lds_bytes, &per_cu); break;
-            case 512: rc = resident_blocks<512>(lds_bytes, &per_cu); break;
-            case 768: rc = resident_blocks<768>(lds_bytes, &per_cu); break;
-            default:  rc = resident_blocks<1024>(lds_bytes, &per_cu); break;
+            case 256: rc = resident_blocks<256>(lds_bytes + g->lds_pad, &per_cu); break;
+            case 512: rc = resident_blocks<512>(lds_bytes + g->lds_pad, &per_cu); break;
+            case 768: rc = resident_blocks<768>(lds_bytes + g->lds_pad, &per_cu); break;
+            default:  rc = resident_blocks<1024>(lds_bytes + g->lds_pad, &per_cu); break;
         }
         if (rc) return rc;
         n_wg = g->num_cus * per_cu;
@@ -713,10 +720,10 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
 
     auto launch = [&](int wgs) {
         switch (block_threads) {
-            case 256: return launch_kernel<256>(kp, wgs, lds_bytes, s);
-            case 512: return launch_kernel<512>(kp, wgs, lds_bytes, s);
-            case 768: return launch_kernel<768>(kp, wgs, lds_bytes, s);
-            default:  return launch_kernel<1024>(kp, wgs, lds_bytes, s);
+            case 256: return launch_kernel<256>(kp, wgs, lds_bytes + g->lds_pad, s);
+            case 512: return launch_kernel<512>(kp, wgs, lds_bytes + g->lds_pad, s);
+            case 768: return launch_kernel<768>(kp, wgs, lds_bytes + g->lds_pad, s);
+            default:  return launch_kernel<1024>(kp, wgs, lds_bytes + g->lds_pad, s);
         }
     };
     HIP_TRY(hipEventRecord(g->ev0, s));

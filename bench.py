@@ -59,7 +59,7 @@ WORKLOADS = {
 def kernel_source_sha16() -> str:
     """Identity of the GFPush kernel sources: profiles/*_pmc_summary.json carries the hash it was measured on."""
     h = hashlib.sha256()
-    for f in ("grand_plus_amd/csrc/gfpush_kernels.hpp", "grand_plus_amd/csrc/gfpush.hip"):
+    for f in ("grand_plus_amd/csrc/gfpush_kernels.hpp", "grand_plus_amd/csrc/gfpush_sketch.hpp", "grand_plus_amd/csrc/gfpush.hip"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -200,7 +200,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the augmentation / propagation lines (SURVEY.md 8f)")
-    ap.add_argument("--no-settle", action="store_true", help="skip the untimed settling launches in front of the warmup steps")
+    ap.add_argument("--prewarm", type=int, default=50, help="untimed launches of the first warmup batch in front of the W warmup steps (a fixed count: "
+                    "the same on every rank, no collective); reported as part of warmup_effective")
+    ap.add_argument("--no-settle", action="store_true", help="same as --prewarm 0")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
@@ -316,90 +318,37 @@ def run_rank(args) -> int:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # Settling, before the W warmup steps and outside every clock: on a freshly started GPU box the first tens of seconds can
-    # run several times slower than the steady state (observed on this pool: the first bench process of a box at 120-160 ms
-    # per MAG launch, 4.8x, and 27 ms later in the same process; the launches of such a phase agree with each other).  Repeat
-    # the first warmup batch until two consecutive launches agree within 10 %, agree with the fastest seen so far within
-    # 15 %, and the device delivers what an MI355X delivers in the steady state on two probes that do not depend on any
-    # counter's time base (gp_internal_speed_probe): a dependent integer multiply-add chain in one wave (60.9 iterations per
-    # microsecond at 2.4 GHz: proportional to the shader clock) and a 256 MiB streaming copy (5.1-5.6 TB/s read + write);
-    # for at most 90 s (the slow phases seen lasted 40-55 s from a process's first launch).  Count and last readings are
-    # reported as `settle_steps` / `settle_probe`.
-    settle_steps = 0; settle_probe = None; ref_ms = None; ref_factor = 1.5
-    if not args.no_settle:
-        from grand_plus_amd import _native
-        ALU_REF, COPY_REF = 60.9, 5300.0                  # tools/clock_timeline.py on a settled MI355X box (gpurun_out/clk2.txt)
-        # the same launch as profiled for these kernel sources (profiles/r03_bench_lines.json), when there is one: a launch that
-        # takes more than 1.5x as long is not the steady state, however well it agrees with its neighbours
-        ref_ms = None; ref_factor = 1.5
-        try:
-            ref = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_lines.json"))).get(args.workload, {})
-            if ref.get("config", {}).get("seeds_per_gpu") == per and not (args.block_threads or args.lds_bytes or args.opt):
-                ref_ms = float(ref["roofline"]["kernel_ms_avg"])
-                # other kernel sources than the profiled ones, or a step that ends with a collective: only a gross excess counts
-                if world > 1 or ref.get("roofline", {}).get("kernel_sha16") != kernel_source_sha16():
-                    ref_factor = 2.5
-        except (OSError, ValueError, KeyError):
-            ref_ms = None
-        seen = []
-        t_settle = time.perf_counter()
-        while settle_steps < 2000:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); step(0); b.record(); torch.cuda.synchronize(dev)
-            seen.append(a.elapsed_time(b)); settle_steps += 1
-            alu, gbs = _native.speed_probe(local_rank)
-            settle_probe = {"alu_iters_per_us": round(alu, 1), "copy_gb_s": round(gbs), "shader_clock_mhz": round(_native.shader_clock_mhz(local_rank)),
-                            "launch_ms": round(seen[-1], 3), "profiled_launch_ms": ref_ms}
-            tol = 0.10 if world == 1 else 0.25            # (a step of several ranks ends with a collective)
-            ok = (len(seen) >= 2 and abs(seen[-1] - seen[-2]) <= tol * seen[-1] and seen[-1] <= (1.05 + tol) * min(seen)
-                  and alu >= 0.75 * ALU_REF and gbs >= 0.6 * COPY_REF and (ref_ms is None or world > 1 or seen[-1] <= ref_factor * ref_ms))     # (a step of several ranks ends with the gather: the profiled KERNEL time is compared after the timed block instead)
-            # (the two anomalous blocks seen inside a process began 0.5-1 s after its first launches, behind three fast settling
-            #  launches: settling therefore lasts at least 6 s, so that such a phase begins -- and is waited out -- inside it)
-            ok = ok and time.perf_counter() - t_settle >= 6.0
-            late = time.perf_counter() - t_settle >= (90.0 if world == 1 else 30.0)
-            if world > 1:                       # every rank leaves the loop in the same iteration (step() holds a collective)
-                flag = torch.tensor([1 if ok else 0, 0 if late else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok, late = bool(flag[0].item()), not bool(flag[1].item())
-            if ok or late:
-                break
-    # W untimed warmup steps, then EXACTLY K timed steps between two fences.  One anomaly is handled in the open: on this pool
-    # a timed block now and then runs 4-5x slower than the profiled launch of the same kernel sources although the launches
-    # right before it (settling) and after it (host API) run at the profiled speed and neither probe moves (DESIGN.md
-    # section 4).  When the block's launches average more than `ref_factor` x the profiled launch, the block (warmup + K
-    # steps) is repeated after a 20 s pause, at most twice; every discarded attempt is reported in `discarded_attempts`.
-    discarded = []
-    while True:
-        for i in range(args.warmup):
-            step(i)
-        fence()
-        graph.reset_stats()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        t_start = time.perf_counter()
-        for j in range(args.steps):
-            i = args.warmup + j
-            packed.filled.zero_()
-            ev[j][0].record()                       # torch's current stream == the launch stream
-            compute(shards[i], packed.row, packed.col, packed.val, packed.filled)
-            ev[j][1].record()
-            if world > 1:
-                gather_rows()
-        fence()
-        elapsed = time.perf_counter() - t_start
-        stats = graph.stats()                       # counters of the timed steps on this rank; raises if a row failed
-        kernel_ms = [a.elapsed_time(b) for a, b in ev]
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
-        redo = (not args.no_settle) and ref_ms is not None and avg_ms > ref_factor * ref_ms and len(discarded) < 2
-        if world > 1:                               # every rank repeats or none does
-            flag = torch.tensor([1 if redo else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            redo = bool(flag.item()) and len(discarded) < 2
-        if not redo:
-            break
-        discarded.append({"ms_per_step": round(elapsed / args.steps * 1e3, 3), "kernel_ms_avg": round(avg_ms, 3),
-                          "library_kernel_ms_last": round(float(stats.get("kernel_ms", 0.0)), 3), "profiled_launch_ms": ref_ms})
-        print(f"[bench] rank {rank}: timed block at {avg_ms:.1f} ms per launch against {ref_ms:.1f} ms profiled -- repeating it", file=sys.stderr, flush=True)
-        time.sleep(20.0)
+    # Untimed launches in front of the W warmup steps the driver asks for: a freshly started process spends its first launches on
+    # first-touch page faults of the workspace, code-object upload and clock ramp-up (the first MAG launch takes 38-41 ms against
+    # 27 ms, profiles/r04_slow_phase_run1.jsonl).  A FIXED count -- the same on every rank, no collective, nothing keyed on an
+    # earlier result -- reported in the JSON line as part of `warmup_effective`.  Nothing is ever discarded: the timed block is the
+    # first and only one, and `anomaly` says when it ran more than 1.5x slower than those launches (reported, not acted on).
+    prewarm = 0 if args.no_settle else max(0, args.prewarm)
+    pre_ms = []
+    for _ in range(prewarm):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); step(0); b.record(); torch.cuda.synchronize(dev)
+        pre_ms.append(a.elapsed_time(b))
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    graph.reset_stats()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for j in range(args.steps):
+        i = args.warmup + j
+        packed.filled.zero_()
+        ev[j][0].record()                       # torch's current stream == the launch stream
+        compute(shards[i], packed.row, packed.col, packed.val, packed.filled)
+        ev[j][1].record()
+        if world > 1:
+            gather_rows()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    stats = graph.stats()                       # counters of the timed steps on this rank; raises if a row failed
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    pre_med = sorted(pre_ms[len(pre_ms) // 2:])[len(pre_ms[len(pre_ms) // 2:]) // 2] if pre_ms else None     # median of the later half
     per_rank_ms = [round(avg_ms, 3)]
     if world > 1:
         red_dev = dev if backend == "nccl" else "cpu"
@@ -421,7 +370,9 @@ def run_rank(args) -> int:
         sha = kernel_source_sha16()
         line = {
             "metric": "propagation-matrix rows/sec (whole node)", "value": round(value, 1), "unit": "rows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps, "settle_probe": settle_probe, "discarded_attempts": discarded,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": args.warmup + prewarm,
+            "prewarm_step_ms_median": None if pre_med is None else round(pre_med, 3),
+            "anomaly": bool(pre_med is not None and world == 1 and avg_ms > 1.5 * pre_med),
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if source.startswith("synth:") else "fixture graph (tests/golden), seeds cycled",
@@ -433,7 +384,8 @@ def run_rank(args) -> int:
                        "sharding": "seeds block-partitioned, CSR replicated" + (", 1 RCCL all-gather of packed rows per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "gfpush_kernel", "kernel_ms_avg": round(avg_ms, 3), "kernel_sha16": sha,
+                         "kernel": "gfpush_sk_kernel (+ gfpush_retry_kernel for the rows it hands back)" if stats.get("kernel") == 2 else "gfpush_kernel",
+                         "kernel_ms_avg": round(avg_ms, 3), "kernel_sha16": sha,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "bytes_per_row": round(bytes_per_launch / per, 1)},
             # the path is not HBM-bound: second yardstick = residue-table inserts per clock and CU against the
@@ -450,7 +402,10 @@ def run_rank(args) -> int:
                        "lds_levels": stats["lds_levels"], "global_levels": stats["global_levels"],
                        "workgroups": stats["workgroups"], "block_threads": stats["block_threads"],
                        "lds_bytes": stats["lds_bytes"], "workspace_gb": round(stats["workspace_bytes"] / 2**30, 2),
-                       "retried_rows": stats["retried_rows"], "max_level_edges": stats["max_level_edges"],
+                       "retried_rows": stats["retried_rows"], "kernel_kind": stats.get("kernel"),
+                       "sketch_candidate_edge_fraction": round(stats.get("sketch_candidate_edges", 0) / max(stats["edges"], 1), 4),
+                       "sketch_second_rounds_per_row": round(stats.get("sketch_second_sweeps", 0) / max(stats["rows"], 1), 4),
+                       "max_level_edges": stats["max_level_edges"],
                        "max_log_records": stats["max_log_records"],
                        "graph_gen_s": round(t_gen, 2), "csr_upload_s": round(t_upload, 3)},
         }
@@ -458,9 +413,14 @@ def run_rank(args) -> int:
         # same command, tools/collect_pmc.sh) and committed under profiles/ together with the hash of the kernel
         # sources it was measured on; a bench run cannot profile itself, and a profile of OTHER sources is not reported.
         try:
-            pname = "r03_mag_pmc_summary.json"
-            prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
-            if args.workload == prof.get("workload") and per == prof.get("seeds_per_gpu") and world == 1:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc_summary.json")), reverse=True)
+            seen_other = None
+            for path in cands:                  # newest round first: the profile of THESE kernel sources, if there is one
+                prof = json.load(open(path))
+                if args.workload != prof.get("workload") or per != prof.get("seeds_per_gpu") or world != 1:
+                    continue
+                pname = os.path.basename(path)
                 if prof.get("kernel_sha16") == sha:
                     dd = prof["derived"]
                     line["roofline"]["traffic"] = int(dd["hbm_read_bytes_corrected"] + dd["hbm_write_bytes"])
@@ -468,8 +428,11 @@ def run_rank(args) -> int:
                     line["roofline"]["traffic_source"] = (f"profiles/{pname}: rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command on the same "
                                                           "kernel sources; reads = TCC_EA0_RDREQ x 128 B (one request per 128-byte L2 line on gfx950, "
                                                           "calibrated by tools/fetch_calib.sh -> profiles/r03_fetch_calib.json; FETCH_SIZE tallies 64), writes = WRITE_SIZE")
-                else:
-                    line["roofline"]["traffic_source"] = f"none: profiles/{pname} was measured on kernel sources {prof.get('kernel_sha16')}, this run is {sha}"
+                    seen_other = None
+                    break
+                seen_other = seen_other or f"none: profiles/{pname} was measured on kernel sources {prof.get('kernel_sha16')}, this run is {sha}"
+            if seen_other:
+                line["roofline"]["traffic_source"] = seen_other
         except (OSError, KeyError, ValueError):
             pass
         if stats.get("diag_ticks_total"):

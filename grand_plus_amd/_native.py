@@ -27,7 +27,7 @@ EXPORTS = (
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
-    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_clock_mhz", "gp_internal_speed_probe",
+    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan",
 )
 
 
@@ -45,6 +45,8 @@ class GpStats(ctypes.Structure):
         ("diag_ticks_scan_hbm", ctypes.c_int64), ("diag_ticks_expand_hbm", ctypes.c_int64),
         ("diag_sub", ctypes.c_int64 * 16),
         ("retried_rows", ctypes.c_int64), ("max_level_edges", ctypes.c_int64), ("max_log_records", ctypes.c_int64),
+        ("kernel", ctypes.c_int32), ("sketch_pad", ctypes.c_int32),
+        ("sketch_candidate_edges", ctypes.c_int64), ("sketch_second_sweeps", ctypes.c_int64),
     ]
 
     def as_dict(self):
@@ -119,11 +121,7 @@ def lib():
     L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
-    L.gp_internal_speed_probe.restype = ctypes.c_int
-    L.gp_internal_speed_probe.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-    L.gp_internal_clock_mhz.restype = ctypes.c_int
-    L.gp_internal_clock_mhz.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    if L.gp_abi_version() != 2:
+    if L.gp_abi_version() != 3:
         raise RuntimeError("libgrandplus.so ABI version mismatch")
     _LIB = L
     return L
@@ -140,17 +138,3 @@ def raise_for_status(status: int):
     if status == GP_ERR_NOMEM:
         raise MemoryError(detail)
     raise RuntimeError(detail)
-
-
-def shader_clock_mhz(device: int = 0) -> float:
-    """The shader clock `device` runs at right now (measurement aid of bench.py; gp_internal_clock_mhz)."""
-    mhz = ctypes.c_double(0.0)
-    raise_for_status(lib().gp_internal_clock_mhz(int(device), ctypes.byref(mhz)))
-    return float(mhz.value)
-
-
-def speed_probe(device: int = 0):
-    """(ALU iterations per us of a dependent multiply-add chain in one wave, GB/s of a 256 MiB streaming copy) on `device`."""
-    alu, gbs = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    raise_for_status(lib().gp_internal_speed_probe(int(device), ctypes.byref(alu), ctypes.byref(gbs)))
-    return float(alu.value), float(gbs.value)

@@ -7,6 +7,7 @@
 // scratch area from rigorous bounds (below), launches ONE persistent kernel
 // (gfpush_kernels.hpp) on the caller's stream and brackets it with HIP events.
 #include "gfpush_kernels.hpp"
+#include "gfpush_sketch.hpp"
 #include "grandplus.h"
 
 #include <dlfcn.h>
@@ -70,9 +71,10 @@ struct Slabs {
 
 struct Workspace {
     void* base = nullptr; size_t bytes = 0;
-    Slabs est;                    // first launch: every workgroup, slabs sized from an estimate of a row's needs
-    Slabs big;                    // retry launch: a few workgroups, slabs sized from the rigorous bounds (n_wg == 0: not needed)
-    uint32_t* retry_list = nullptr; int64_t retry_cap = 0;
+    Slabs skl;                    // sketch kernel (gfpush_sketch.hpp): every workgroup; push lists + boundary tables + the per-edge log (n_wg == 0: not in use)
+    Slabs est;                    // general kernel: slabs sized from an estimate of a row's needs (every workgroup; a quarter of them when it only re-runs what the sketch kernel handed back)
+    Slabs big;                    // last launch: a few workgroups, slabs sized from the rigorous bounds (n_wg == 0: not needed)
+    uint32_t* retry_list = nullptr; uint32_t* retry_list2 = nullptr; int64_t retry_cap = 0;
     bool dirty = true;            // HBM residue tables need (re)initialising before the next launch
 };
 
@@ -90,6 +92,9 @@ struct gp_graph {
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
     int lds_pad = 0; int pretouch = 0;                                    // experiment knobs: extra dynamic LDS per workgroup that the tables do not use (forces fewer workgroups per CU); memset the workspace when it is allocated
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
+    int kernel = 0;                                                        // option: 0 = choose per call, 1 = general kernel, 2 = sketch kernel whenever the call allows it
+    int sk_block = 0, sk_lg_mu = 0, sk_lg_mr = 0, sk_target = 0;           // options: geometry of the sketch kernel (0 = default)
+    int est_kind = 0; int last_kind = 1;                                   // which kernel the running estimate / the last call belongs to
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
     double est_rmax = -1.0; int est_n_coef = 0;                            // the call parameters that estimate belongs to
@@ -143,6 +148,22 @@ template <int BLOCK> int resident_blocks(int lds_bytes, int* out) {
     return GP_OK;
 }
 
+#ifndef GP_DIAG
+template <int BLOCK> int launch_sk(const KParams& kp, int n_wg, int lds_bytes, hipStream_t s) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gfpush_sk_kernel<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(gfpush_sk_kernel<BLOCK>, dim3(n_wg), dim3(BLOCK), lds_bytes, s, kp);
+    HIP_TRY(hipGetLastError());
+    return GP_OK;
+}
+template <int BLOCK> int resident_sk(int lds_bytes, int* out) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gfpush_sk_kernel<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gfpush_sk_kernel<BLOCK>, BLOCK, lds_bytes));
+    *out = std::max(nb, 1);
+    return GP_OK;
+}
+#endif
+
 void free_workspace(Workspace& w) {
     if (w.base) (void)hipFree(w.base);
     w = Workspace();
@@ -178,6 +199,16 @@ Slabs slab_sizes(const gp_graph* g, int n_coef, double e_max, double log_records
     return sl;
 }
 
+// The sketch kernel's slab: two push lists, two boundary tables and the per-EDGE reserve log (`log_records` = edges of a row).
+Slabs sk_slab_sizes(const gp_graph* g, double e_max, double log_records) {
+    Slabs sl;
+    sl.log_cap = ((u64)(log_records + 64.0) + 3) & ~3ull;
+    sl.push_cap = (u64)(std::min((double)g->n_nodes, e_max) + 2.0);       // one entry per pushing node, at most one per edge
+    const double e_bt = std::min(level_edge_bound_of(g), std::max(8.0 * e_max, 1048576.0));
+    sl.bt_cap = (((u64)std::max(e_max, e_bt) >> kUnitShift) + 4) & ~1ull;
+    return sl;
+}
+
 double level_edge_bound(const gp_graph* g, double rmax) {
     double e = (double)g->nnz;
     if (rmax > 0.0) e = std::min(e, std::floor(1.001 / rmax) + 16.0);
@@ -190,7 +221,9 @@ double level_edge_bound(const gp_graph* g, double rmax) {
 // estimate that starts at max(32 Ki edges per level, bound / 4), is capped so that the slabs fit HALF the budget, and grows
 // from the maxima the kernel observes -- and a handful of workgroups of a second launch hold bound-sized slabs for the rows
 // that outgrow the estimate (they are detected exactly as before and moved to a retry list instead of failing).
-int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_seeds) {
+int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_seeds, int sk_wg) {
+    // sk_wg > 0: the sketch kernel runs the call on sk_wg workgroups (own, smaller slabs: no HBM residue table, no candidate /
+    // bucket buffers); the general kernel then only re-runs the rows handed back, on n_wg workgroups.
     const double bound = level_edge_bound(g, rmax);
     {
         const Slabs worst = slab_sizes(g, n_coef, bound, 0.0);
@@ -203,26 +236,35 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)(0.9 * (double)(free_b + g->ws.bytes)));
         else (void)hipGetLastError();
     }
-    if (g->est_rmax != rmax || g->est_n_coef != n_coef) {            // a new recipe: forget the running estimate
-        g->est_rmax = rmax; g->est_n_coef = n_coef; g->est_edges = 0.0; g->est_log = 0.0;
+    const int kind = sk_wg > 0 ? 2 : 1;
+    if (g->est_rmax != rmax || g->est_n_coef != n_coef || g->est_kind != kind) {   // a new recipe (or the other kernel, whose log counts edges): forget the running estimate
+        g->est_rmax = rmax; g->est_n_coef = n_coef; g->est_kind = kind; g->est_edges = 0.0; g->est_log = 0.0;
         g->est_recipe_changed = true;                                // (the observed maxima on the device belong to the old recipe)
     }
     double e_est = g->est_level_edges > 0 ? (double)g->est_level_edges
                                           : std::max(g->est_edges, std::max(32768.0, bound / 4.0));
     e_est = std::min(e_est, bound);
     double log_est = e_est >= bound ? 0.0 : std::max(g->est_log, 4.0 * e_est);
-    Slabs est = slab_sizes(g, n_coef, e_est, log_est);
-    while ((double)est.per_wg() * n_wg > 0.5 * (double)budget && e_est > 4096.0) {     // shrink the slabs, not the launch
-        e_est *= 0.75; log_est = std::max(4096.0, 0.75 * (log_est > 0.0 ? log_est : (double)est.log_cap));
+    Slabs est, skl;
+    auto plan = [&]() {
         est = slab_sizes(g, n_coef, e_est, log_est);
+        if (sk_wg > 0) skl = sk_slab_sizes(g, e_est, log_est > 0.0 ? log_est : (double)n_coef * e_est);
+        return (double)est.per_wg() * n_wg + (sk_wg > 0 ? (double)skl.per_wg() * sk_wg : 0.0);
+    };
+    while (plan() > 0.5 * (double)budget && e_est > 4096.0) {        // shrink the slabs, not the launch
+        e_est *= 0.75; log_est = std::max(4096.0, 0.75 * (log_est > 0.0 ? log_est : (double)est.log_cap));
     }
-    if ((double)est.per_wg() * n_wg > 0.5 * (double)budget) n_wg = (int)std::max<size_t>(1, budget / 2 / est.per_wg());
+    if (plan() > 0.5 * (double)budget) {
+        if (sk_wg > 0) return fail(GP_ERR_NOMEM, "workspace_mb too small for the sketch kernel's slabs");
+        n_wg = (int)std::max<size_t>(1, budget / 2 / est.per_wg());
+    }
     g->cur_e_est = e_est; g->cur_log_est = log_est;
-    est.n_wg = n_wg;
+    est.n_wg = n_wg; skl.n_wg = sk_wg;
     Slabs big;                                                       // needed only if the estimate is below the bound
     if (e_est < bound || log_est > 0.0) {
         big = slab_sizes(g, n_coef, bound, 0.0);
-        const size_t left = budget - std::min(budget, est.per_wg() * (size_t)n_wg);
+        const size_t used = est.per_wg() * (size_t)n_wg + skl.per_wg() * (size_t)sk_wg;
+        const size_t left = budget - std::min(budget, used);
         int nb = (int)std::min<size_t>(8, left / std::max<size_t>(1, big.per_wg()));
         if (nb < 1) {                                                // not even one worst-case slab fits: give it what is left
             double e_big = bound;
@@ -234,10 +276,11 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
     }
 
     Workspace& w = g->ws;
-    const bool fits = w.base && w.est.covers(est) && w.big.covers(big) && w.retry_cap >= n_seeds;
+    const bool fits = w.base && w.est.covers(est) && w.big.covers(big) && w.skl.covers(skl) && w.retry_cap >= n_seeds;
     if (!fits) {
         free_workspace(w);
-        const size_t total = est.per_wg() * (size_t)est.n_wg + big.per_wg() * (size_t)big.n_wg + 4 * (size_t)std::max<int64_t>(n_seeds, 1) + 4096 + 1024;
+        const size_t total = est.per_wg() * (size_t)est.n_wg + big.per_wg() * (size_t)big.n_wg + skl.per_wg() * (size_t)skl.n_wg +
+                             8 * (size_t)std::max<int64_t>(n_seeds, 1) + 3 * 4096 + 1024;
         hipError_t e = hipMalloc(&w.base, total);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -246,9 +289,11 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
         w.bytes = total;
         if (g->pretouch && hipMemset(w.base, 0, total) != hipSuccess) (void)hipGetLastError();
         char* p = (char*)w.base;
+        w.skl = skl; if (skl.n_wg > 0) p += w.skl.carve(p, skl.n_wg);
         w.est = est; p += w.est.carve(p, est.n_wg);
         w.big = big; if (big.n_wg > 0) p += w.big.carve(p, big.n_wg);
-        w.retry_list = (uint32_t*)p; w.retry_cap = std::max<int64_t>(n_seeds, 1);
+        w.retry_cap = std::max<int64_t>(n_seeds, 1);
+        w.retry_list = (uint32_t*)p; w.retry_list2 = w.retry_list + w.retry_cap;
         w.dirty = true;
     }
     return GP_OK;
@@ -532,6 +577,18 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "lds_pad") {
         if (value < 0 || value > 120 * 1024) return fail(GP_ERR_INVALID_ARG, "lds_pad must be in [0, 122880]");
         g->lds_pad = (int)(value & ~15ll);       // dynamic LDS the tables do not use: fewer workgroups per CU at the same table size (occupancy experiments)
+    } else if (k == "kernel") {
+        if (value < 0 || value > 2) return fail(GP_ERR_INVALID_ARG, "kernel must be 0 (automatic), 1 (general) or 2 (sketch)");
+        g->kernel = (int)value;
+    } else if (k == "sk_block_threads") {
+        if (value != 0 && value != 512 && value != 768) return fail(GP_ERR_INVALID_ARG, "sk_block_threads must be 0, 512 or 768");
+        g->sk_block = (int)value;
+    } else if (k == "sk_lg_mu" || k == "sk_lg_mr") {
+        if (value != 0 && (value < 8 || value > 14)) return fail(GP_ERR_INVALID_ARG, "%s must be 0 or in [8, 14]", key);
+        (k == "sk_lg_mu" ? g->sk_lg_mu : g->sk_lg_mr) = (int)value;
+    } else if (k == "sk_target") {
+        if (value < 0 || value > 4096) return fail(GP_ERR_INVALID_ARG, "sk_target must be in [0, 4096]");
+        g->sk_target = (int)value;
     } else if (k == "pretouch") {
         g->pretouch = value ? 1 : 0;             // memset the whole workspace when it is allocated (slow-phase experiment)
     } else if (k == "max_workgroups") {
@@ -618,6 +675,50 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     // and tau is read off a 16x finer histogram).  Measured on MI355X (round 3, 65 536 rows) against 2 x 768 x 80 KB:
     // MAG-shape +2.9 %, Reddit-shape +1.3 %, Pubmed +13 %, Cora +10 %.  K > 128 keeps 2 x 768 (sel[K] eats the table).
     bool three_per_cu = two_per_cu && K <= 128;
+
+    // ---- which kernel.  The sketch kernel (gfpush_sketch.hpp) keeps exact fp64 accumulators only for the targets that may
+    // push and reads the top-K off a cumulative upper-bound table; it needs coef >= 0 (upper bounds add up), a recipe that
+    // fits its control block, and a threshold the fixed-point sketch can resolve.  Rows it cannot finish come back on a
+    // retry list and the general kernel runs them.
+    bool use_sk = false;
+    double coef_sum = 0.0;
+#ifndef GP_DIAG
+    {
+        bool ok = g->kernel != 1 && n_coef <= kSkMaxCoef && K <= 128 && rmax * 2147483648.0 >= 64.0 && !g->force_global && !g->exact_stats &&
+                  n_seeds > 0;
+        for (int i = 0; i < n_coef; ++i) { if (coef[i] < 0.0) ok = false; coef_sum += coef[i]; }
+        if (!(coef_sum < 1.0e6)) ok = false;
+        // automatic: the recipes whose push test filters (rmax >= 5e-6; at 1e-6 and below most of a frontier pushes and the
+        // sketch has nothing to remove) on graphs too large for direct-indexed tables
+        const bool auto_sk = rmax >= 5e-6 && g->n_nodes >= 16384;
+        use_sk = ok && (g->kernel == 2 || auto_sk);
+    }
+#endif
+    int sk_block = 0, sk_lds = 0, sk_wg = 0; u32 sk_lg_mu = 0, sk_lg_mr = 0, sk_cx = 0;
+#ifndef GP_DIAG
+    if (use_sk) {
+        sk_block = g->sk_block ? g->sk_block : 768;
+        sk_lds = sk_block == 512 ? kThreeLds : 80 * 1024;
+        sk_lg_mu = (u32)(g->sk_lg_mu ? g->sk_lg_mu : (sk_block == 512 ? 12 : 13));
+        sk_lg_mr = (u32)(g->sk_lg_mr ? g->sk_lg_mr : (sk_block == 512 ? 12 : 13));
+        const int64_t x_bytes = (int64_t)sk_lds - kCtlBytes - (4ll << sk_lg_mu);
+        sk_cx = x_bytes > 0 ? (u32)(x_bytes / 12) & ~3u : 0u;
+        // the exact table, and the aggregation table TOP-K builds behind its reserve sketch in the same bytes, need >= kMinCap slots
+        const int64_t ca = ((4ll << sk_lg_mu) + 12ll * sk_cx - (4ll << sk_lg_mr) - 16ll * ((int64_t)kSkTie + K)) / 12;
+        if (sk_cx < kMinCap || ca < (int64_t)kMinCap) {
+            if (g->kernel == 2 && (g->sk_lg_mu || g->sk_lg_mr)) return fail(GP_ERR_INVALID_ARG, "sketch sizes leave no room for the exact table (sk_lg_mu %u, sk_lg_mr %u)", sk_lg_mu, sk_lg_mr);
+            use_sk = false;
+        }
+    }
+    if (use_sk) {
+        int per_cu = 1;
+        rc = sk_block == 512 ? resident_sk<512>(sk_lds + g->lds_pad, &per_cu) : resident_sk<768>(sk_lds + g->lds_pad, &per_cu);
+        if (rc) return rc;
+        sk_wg = g->num_cus * per_cu;
+        if (g->max_workgroups > 0) sk_wg = std::min(sk_wg, g->max_workgroups);
+        sk_wg = (int)std::max<int64_t>(1, std::min<int64_t>(sk_wg, n_seeds));
+    }
+#endif
     int block_threads = 0, lds_bytes = 0, n_wg = 0;
     u32 lds_slots = 0;
     for (;;) {
@@ -651,9 +752,11 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         if (rc) return rc;
         n_wg = g->num_cus * per_cu;
         if (g->max_workgroups > 0) n_wg = std::min(n_wg, g->max_workgroups);
+        if (use_sk) n_wg = std::min(n_wg, std::max(8, g->num_cus));     // the general kernel only re-runs what the sketch kernel hands back
         n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(n_wg, n_seeds));
-        rc = ensure_workspace(g, n_coef, rmax, n_wg, n_seeds);
+        rc = ensure_workspace(g, n_coef, rmax, n_wg, n_seeds, use_sk ? sk_wg : 0);
         if (rc) return rc;
+        if (use_sk) break;
         // the workspace budget could not hold two workgroups per CU: one big workgroup per CU is better than
         // a half-empty chip
         if (three_per_cu && g->ws.est.n_wg < n_wg && g->ws.est.n_wg < 3 * g->num_cus) { three_per_cu = false; continue; }
@@ -676,7 +779,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * kNumCounters, s));
         g->reset_pending = false; g->rows_total = 0;
     } else {
-        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * (kRetryRows + 1), s));   // the two queue heads and the retry count
+        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * (kRetryRows2 + 1), s));   // the queue heads and the retry counts
         if (g->est_recipe_changed)                                                          // maxima of another recipe must not size this one's slabs
             HIP_TRY(hipMemsetAsync(g->d_counters + kMaxLevelEdges, 0, sizeof(u64) * 2, s));
     }
@@ -690,6 +793,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     }
 
     KParams kp;
+    std::memset(&kp, 0, sizeof kp);
     kp.indptr = g->d_indptr; kp.indices = g->d_indices; kp.n_nodes = (int)g->n_nodes; kp.nnz = (int)g->nnz;
     kp.deg_shift = g->deg_shift; kp.node_mask = g->node_mask; kp.deg_sat = g->deg_sat;
     kp.seeds = d_seeds; kp.n_seeds = n_seeds;
@@ -703,10 +807,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         kp.cand = sl.cand; kp.cand_cap = sl.cand_cap;
         kp.bucket = sl.bucket; kp.bucket_cap = sl.bucket_cap;
     };
-    use_slabs(w.est);
     const bool two_tier = w.big.n_wg > 0;
-    kp.row_map = nullptr; kp.n_rows_dev = nullptr; kp.queue_counter = kQueue;
-    kp.retry_list = two_tier ? w.retry_list : nullptr;
     kp.counters = g->d_counters;
     kp.lds_slots = lds_slots;
     kp.force_global = g->force_global;
@@ -727,7 +828,10 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         }
     };
     HIP_TRY(hipEventRecord(g->ev0, s));
-    if (n_seeds > 0) {
+    if (n_seeds > 0 && !use_sk) {
+        use_slabs(w.est);
+        kp.row_map = nullptr; kp.n_rows_dev = nullptr; kp.queue_counter = kQueue;
+        kp.retry_list = two_tier ? w.retry_list : nullptr; kp.retry_counter = kRetryRows;
         rc = launch(n_wg);
         if (rc) return rc;
         if (two_tier) {
@@ -740,14 +844,48 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
             if (rc) return rc;
         }
     }
+#ifndef GP_DIAG
+    if (n_seeds > 0 && use_sk) {
+        // 1. the sketch kernel over every row; what it cannot finish goes to retry_list (count in kRetryRows)
+        use_slabs(w.skl);
+        kp.row_map = nullptr; kp.n_rows_dev = nullptr; kp.queue_counter = kQueue;
+        kp.retry_list = w.retry_list; kp.retry_counter = kRetryRows;
+        kp.sk_lg_mu = sk_lg_mu; kp.sk_lg_mr = sk_lg_mr; kp.sk_cx = sk_cx;
+        kp.sk_target = (u32)(g->sk_target > 0 ? g->sk_target : 2 * K);
+        kp.sk_rscale = 2147483648.0 / std::max(1.0, coef_sum);
+        {   // rmax * 2^31 * (1 - 2^-10), rounded DOWN to fp32: cell >= packed degree * this is necessary for r >= rmax * deg
+            float t = (float)(rmax * 2147483648.0 * (1.0 - 1.0 / 1024.0));
+            while ((double)t > rmax * 2147483648.0 * (1.0 - 1.0 / 1024.0)) t = std::nextafterf(t, 0.0f);
+            kp.sk_thr_f = t;
+        }
+        rc = sk_block == 512 ? launch_sk<512>(kp, sk_wg, sk_lds + g->lds_pad, s) : launch_sk<768>(kp, sk_wg, sk_lds + g->lds_pad, s);
+        if (rc) return rc;
+        // 2. the general kernel over that list (a quarter of the chip: the list is a per-cent of the call); rows that outgrow
+        //    ITS estimate-sized slabs go to retry_list2 ...
+        use_slabs(w.est);
+        kp.row_map = w.retry_list; kp.n_rows_dev = g->d_counters + kRetryRows; kp.queue_counter = kQueueRetry;
+        kp.retry_list = two_tier ? w.retry_list2 : nullptr; kp.retry_counter = kRetryRows2;
+        rc = launch(n_wg);
+        if (rc) return rc;
+        if (two_tier) {     // 3. ... which the bound-sized slabs take
+            use_slabs(w.big);
+            kp.row_map = w.retry_list2; kp.n_rows_dev = g->d_counters + kRetryRows2; kp.queue_counter = kQueueRetry2;
+            kp.retry_list = nullptr;
+            rc = launch(w.big.n_wg);
+            if (rc) return rc;
+        }
+    }
+#endif
     HIP_TRY(hipEventRecord(g->ev1, s));
     HIP_TRY(hipMemcpyAsync(g->h_counters, g->d_counters, sizeof(u64) * kNumCounters, hipMemcpyDeviceToHost, s));
     g->launched = true; g->last_stream = s; g->last_call_rows = n_seeds;
     std::memset(&g->last, 0, sizeof g->last);
     g->rows_total += n_seeds;
     g->last.rows = g->rows_total;
-    g->last.workgroups = n_wg; g->last.block_threads = block_threads;
-    g->last.lds_bytes = lds_bytes; g->last.lds_slots = (int)lds_slots;
+    g->last_kind = use_sk ? 2 : 1;
+    g->last.kernel = g->last_kind;
+    g->last.workgroups = use_sk ? sk_wg : n_wg; g->last.block_threads = use_sk ? sk_block : block_threads;
+    g->last.lds_bytes = use_sk ? sk_lds : lds_bytes; g->last.lds_slots = use_sk ? (int)sk_cx : (int)lds_slots;
     g->last.workspace_bytes = (int64_t)w.bytes;
     return GP_OK;
 }
@@ -786,6 +924,8 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     s.retried_rows = (int64_t)g->h_counters[kRetriedTotal];
     s.max_level_edges = (int64_t)g->h_counters[kMaxLevelEdges];
     s.max_log_records = (int64_t)g->h_counters[kMaxLogRecords];
+    s.sketch_candidate_edges = (int64_t)g->h_counters[kSkCandEdges];
+    s.sketch_second_sweeps = (int64_t)g->h_counters[kSkSweep2];
     // grow the estimate the next call's slabs are sized from: 1.5 x the largest level / log seen so far
     // (gp_gfpush_device does the same, and the doubling after a call with > 2 % retried rows, when it starts)
     if (g->est_level_edges == 0) {
@@ -927,6 +1067,7 @@ int replicate_part(gp_graph* g, int d) {
     q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
     q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
     q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges; q->seedrow = src->seedrow; q->solo_levels = src->solo_levels;
+    q->kernel = src->kernel; q->sk_block = src->sk_block; q->sk_lg_mu = src->sk_lg_mu; q->sk_lg_mr = src->sk_lg_mr; q->sk_target = src->sk_target; q->lds_pad = src->lds_pad;
     const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));

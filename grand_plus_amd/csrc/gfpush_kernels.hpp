@@ -89,25 +89,15 @@ constexpr int    kFlatW      = GP_FLAT_W;       // EXPAND: 64-edge windows a wav
 #endif
 #ifdef GP_DIAG
 constexpr int    kCtlStruct  = 4096;    // (diagnostic build: + per-barrier-site wait counters)
+#elif defined(GP_SK_TIMING)
+constexpr int    kCtlStruct  = 2048;    // (sketch kernel with phase stamps, tools/sk_phases.py)
 #else
 constexpr int    kCtlStruct  = 1280;    // control block at the start of dynamic LDS ...
 #endif
 constexpr int    kCtlBytes   = kCtlStruct + 16 * 64 * kFlatW;   // ... followed by 64*kFlatW flag bytes per wave (edge_stream)
 constexpr int    kThreeLds   = 53248;   // dynamic LDS of a workgroup when three share a CU (160 KB / 3, allocation granularity)
-#ifndef GP_RATIO_EST
-#define GP_RATIO_EST 1
-#endif
 #ifndef GP_TOPK_UF
 #define GP_TOPK_UF 12
-#endif
-#ifndef GP_HEAVY_USE
-#define GP_HEAVY_USE 1
-#endif
-#ifndef GP_HEAVY_STORE
-#define GP_HEAVY_STORE 1
-#endif
-#ifndef GP_HEAVY
-#define GP_HEAVY 1                 // TOP-K threshold computed during the level loop + heavy list (0: TOP-K sweeps the log for claims)
 #endif
 #ifndef GP_MIN_CAP
 #define GP_MIN_CAP 1024
@@ -123,12 +113,6 @@ constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts w
 #ifndef GP_LOAD_NUM
 #define GP_LOAD_NUM 3u          // a level is expanded in one pass while its edge count is <= GP_LOAD_NUM / GP_LOAD_DEN of the table's slots
 #define GP_LOAD_DEN 4u
-#endif
-#ifndef GP_EVEN_WALK
-#define GP_EVEN_WALK 0          // capacities that give every wave of SCAN the same number of 256-slot steps: MAG -1.3 %, Reddit -1.4 %, Pubmed -1.2 % (the smaller table costs more than the even walk saves)
-#endif
-#ifndef GP_SOLO
-#define GP_SOLO 1
 #endif
 #ifndef GP_BUCKET_MIN
 #define GP_BUCKET_MIN 4            // (3 until three workgroups shared a CU: at 52 KB three partition passes beat the buckets, MAG +1.8 %, Reddit +2.8 %)
@@ -238,10 +222,12 @@ __device__ __forceinline__ u32 wave_sum32(u32 x) {           // sum over the wav
 }
 
 enum Counter { kQueue = 0, kQueueRetry, kRetryRows,          // zeroed at every call: row queue heads of the two launches, rows handed to the retry launch
+               kQueueRetry2, kRetryRows2,                     // ... and of the third launch of a sketch-kernel call (sketch -> general -> general with bound-sized slabs)
                kMaxLevelEdges, kMaxLogRecords,                // observed maxima (atomic max): what the next call's slabs are sized from
                kRetriedTotal,                                 // rows the retry launches have taken since the last reset
                kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
                kGlobalLevels, kFailedRows, kDegLookups,
+               kSkCandEdges, kSkSweep2,                        // sketch kernel (gfpush_sketch.hpp): edges that reached the exact table, rows whose TOP-K needed a second sweep
                kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
                kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
                kDiagX0, kDiagXLast = kDiagX0 + 255,   // GP_DIAG: [0] wave cycles, [1] cycles waves spent at barriers, [2] barriers; [16 + 6*lvl + k] per level:
@@ -307,6 +293,11 @@ struct KParams {
     // rigorous bounds) takes its rows from that list: row_map / n_rows_dev are then set, retry_list is NULL and a
     // row that still does not fit is reported (GP_ERR_OVERFLOW).
     const u32* row_map; const u64* n_rows_dev; u32* retry_list; int queue_counter;
+    int retry_counter; int pad_rc;        // the counter that numbers retry_list's entries (kRetryRows / kRetryRows2)
+    // sketch kernel (gfpush_sketch.hpp): log2 cells of the level sketch U and of the reserve sketch R (built by TOP-K in the level
+    // tables' bytes), slots of the exact table X, the cell rank TOP-K reads its first threshold at, rmax * 2^31 * (1 - 2^-10)
+    // rounded down (the push bound in sketch units per unit of packed degree), the reserve-sketch scale 2^31 / max(1, sum of coef)
+    u32 sk_lg_mu, sk_lg_mr, sk_cx, sk_target; float sk_thr_f; int sk_pad; double sk_rscale;
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
 // The launch parameters where the hardware put them: the kernel argument segment (KParams is the kernels' only argument),
@@ -321,14 +312,6 @@ __device__ __forceinline__ KP kparams() {
 
 // ---------------------------------------------------------------- small helpers
 // Multiplicative (Fibonacci-style) hashes; slot_of() consumes the HIGH bits.
-#ifndef GP_CHEAP_HASH
-#define GP_CHEAP_HASH 0
-#endif
-#if GP_CHEAP_HASH
-// One multiply each (32-bit integer multiplies are quarter-rate instructions, and EXPAND hashes every edge twice)
-__device__ __forceinline__ u32 hash_a(u32 k) { return k * 0x9E3779B1u; }
-__device__ __forceinline__ u32 hash_b(u32 k) { const u32 h = k * 0x7FEB352Du; return h ^ (h << 13); }
-#else
 __device__ __forceinline__ u32 hash_a(u32 k) {            // residue / aggregation tables
     k *= 0x9E3779B1u; k ^= k >> 15; k *= 0x85EBCA77u;
     return k;
@@ -337,7 +320,6 @@ __device__ __forceinline__ u32 hash_b(u32 k) {            // partition choice (i
     k *= 0x7FEB352Du; k ^= k >> 16; k *= 0x846CA68Bu;
     return k;
 }
-#endif
 __device__ __forceinline__ u32 slot_of(u32 h, u32 cap) { return (u32)(((u64)h * cap) >> 32); }
 // Home slot in an LDS table of `cap` slots.  Homes lie in [0, cap - kProbeSpan): a probe sequence then
 // never leaves [0, cap), so the probing loops need no wrap-around (4 VALU per probe); 2 % of a full
@@ -419,9 +401,6 @@ __device__ __forceinline__ void wave_alloc_flags(u32* lds_counter, const bool (&
 // another key (walk on, triangular steps).  No pre-read, no nested branches: the loop body is
 // a handful of instructions, which matters because this path is instruction-issue bound.
 // Keys never revert to EMPTY while inserts are running, so a key ends up in exactly one slot.
-#ifndef GP_ASM_PROBE
-#define GP_ASM_PROBE 1
-#endif
 // The probing loops in gfx950 assembly.  The structurizer turns the C++ loops below into 17-26 instructions per probe
 // (nested exec-mask save/restore blocks, boolean results moved through VGPRs); written by hand a probe is the address,
 // the LDS operation, its wait, two v_cmpx that narrow EXEC to the lanes that must walk on, and the scalar step
@@ -478,50 +457,19 @@ __device__ __forceinline__ int probe_find_asm(const int* keys, u32& slot, int k)
 }
 __device__ __forceinline__ bool res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {
     u32 slot = home_lds((u32)k, cap);
-#if GP_ASM_PROBE
     const int seen = probe_cas_asm(keys, slot, k);
     if (seen != kEmpty && seen != k) return false;
     __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return true;
-#else
-    // A lane leaves the loop as soon as its compare-and-swap hit; `step` is wave-uniform, so the
-    // give-up test is scalar, and failure is encoded in `slot` instead of a second flag.
-#pragma unroll 1
-    for (u32 step = 1;; ++step) {
-        int seen = kEmpty;
-        __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (seen == kEmpty || seen == k) break;
-        if (step == kMaxProbe) { slot = 0xFFFFFFFFu; break; }
-        slot += step;                               // stays below cap, see home_lds
-    }
-    if (slot == 0xFFFFFFFFu) return false;
-    __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return true;
-#endif
 }
 
 // Same insert, reporting failure through a sticky LDS flag instead of a return value: the callers that
 // insert eight keys per step would otherwise fold eight results into a lane mask (4 SALU each).
 __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 cap, int k, double v, u32* flag) {
     u32 slot = home_lds((u32)k, cap);
-#if GP_ASM_PROBE
     const int seen = probe_cas_asm(keys, slot, k);
     if (seen != kEmpty && seen != k) *flag = 1u;
     else __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-#pragma unroll 1
-    for (u32 step = 1;; ++step) {
-        int seen = kEmpty;
-        __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (seen == kEmpty || seen == k) break;
-        if (step == kMaxProbe) { slot = 0xFFFFFFFFu; break; }
-        slot += step;                               // stays below cap, see home_lds
-    }
-    if (slot == 0xFFFFFFFFu) *flag = 1u;
-    else __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 }
 
 // One 64-edge window of EXPAND into an LDS hash table, start to finish in gfx950 assembly: "has an edge" test, partition
@@ -530,9 +478,6 @@ __device__ __forceinline__ void res_add_lds_flag(int* keys, double* vals, u32 ca
 // instructions per window at 1.3 probes, 8 of them scalar; the compiler's version of the same C++ (nested exec save /
 // restore blocks, booleans moved through VGPRs, a uniform branch per condition) executed ~100, 40 of them scalar, and the
 // step loop of EXPAND is where a third of the kernel's instructions are issued.
-#ifndef GP_ASM_WINDOW
-#define GP_ASM_WINDOW 1
-#endif
 __device__ __forceinline__ void insert_window_asm(int* keys, double* vals, u32 cap, u32* flag, int col, double sh, u32 parts, u32 part)
 {
     u32 t, h, slot, seen, st; u64 sv, ent;
@@ -628,94 +573,6 @@ __device__ __forceinline__ void insert_window_solo(int* keys, double* vals, u32 
         : "vcc", "scc", "memory");
 }
 
-// Four inserts per lane with their probing chains INTERLEAVED (the four 64-edge windows of an EXPAND step).  One window's
-// chain is a sequence of dependent LDS round trips whose length is the LONGEST of its 64 lanes' probe sequences (4-7 probes
-// at the load factors of the peak levels), and a step ran four such chains one after the other: more than half of a wave's
-// EXPAND time.  Here every round issues the compare-and-swaps of all four windows back to back, waits once, and narrows each
-// window's mask of still-searching lanes (kept in an SGPR pair: EXEC is loaded from it around the window's instructions), so
-// a step costs max(chain lengths) round trips instead of their sum, at about the same instruction count (39 per round of
-// four vs 10 per probe).  act[w] = lanes that insert in window w.  Sets *flag when a lane exceeds the probe limit.
-#ifndef GP_INSERT4
-#define GP_INSERT4 0          // measured: MAG -5 %, Reddit -3 %, Pubmed -4 % (fewer dependent LDS round trips do not pay for the pressure: the function leaves the caller-saved registers)
-#endif
-__device__ __forceinline__ void insert4_lds(int* keys, double* vals, u32 cap, const int (&k)[4], const double (&v)[4],
-                                            const u64 (&act)[4], u32* flag)
-{
-    if ((act[0] | act[1] | act[2] | act[3]) == 0) return;                  // wave-uniform
-    u32 s0 = home_lds((u32)k[0], cap), s1 = home_lds((u32)k[1], cap), s2 = home_lds((u32)k[2], cap), s3 = home_lds((u32)k[3], cap);
-    u64 m0 = act[0], m1 = act[1], m2 = act[2], m3 = act[3];
-    u32 r0, r1, r2, r3; u64 sv, t; u32 st;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b32 %[st], 1\n"
-        "1:\n\t"
-        "s_mov_b64 exec, %[m0]\n\t"
-        "v_lshl_add_u32 %[r0], %[s0], 2, %[kb]\n\t"
-        "ds_cmpst_rtn_b32 %[r0], %[r0], %[emp], %[k0]\n\t"
-        "s_mov_b64 exec, %[m1]\n\t"
-        "v_lshl_add_u32 %[r1], %[s1], 2, %[kb]\n\t"
-        "ds_cmpst_rtn_b32 %[r1], %[r1], %[emp], %[k1]\n\t"
-        "s_mov_b64 exec, %[m2]\n\t"
-        "v_lshl_add_u32 %[r2], %[s2], 2, %[kb]\n\t"
-        "ds_cmpst_rtn_b32 %[r2], %[r2], %[emp], %[k2]\n\t"
-        "s_mov_b64 exec, %[m3]\n\t"
-        "v_lshl_add_u32 %[r3], %[s3], 2, %[kb]\n\t"
-        "ds_cmpst_rtn_b32 %[r3], %[r3], %[emp], %[k3]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b64 exec, %[m0]\n\t"
-        "v_cmpx_ne_u32 vcc, %[r0], %[k0]\n\t"
-        "v_cmpx_ne_u32 vcc, -1, %[r0]\n\t"
-        "v_add_u32 %[s0], %[st], %[s0]\n\t"
-        "s_mov_b64 %[m0], exec\n\t"
-        "s_mov_b64 exec, %[m1]\n\t"
-        "v_cmpx_ne_u32 vcc, %[r1], %[k1]\n\t"
-        "v_cmpx_ne_u32 vcc, -1, %[r1]\n\t"
-        "v_add_u32 %[s1], %[st], %[s1]\n\t"
-        "s_mov_b64 %[m1], exec\n\t"
-        "s_mov_b64 exec, %[m2]\n\t"
-        "v_cmpx_ne_u32 vcc, %[r2], %[k2]\n\t"
-        "v_cmpx_ne_u32 vcc, -1, %[r2]\n\t"
-        "v_add_u32 %[s2], %[st], %[s2]\n\t"
-        "s_mov_b64 %[m2], exec\n\t"
-        "s_mov_b64 exec, %[m3]\n\t"
-        "v_cmpx_ne_u32 vcc, %[r3], %[k3]\n\t"
-        "v_cmpx_ne_u32 vcc, -1, %[r3]\n\t"
-        "v_add_u32 %[s3], %[st], %[s3]\n\t"
-        "s_mov_b64 %[m3], exec\n\t"
-        "s_or_b64 %[t], %[m0], %[m1]\n\t"
-        "s_or_b64 vcc, %[m2], %[m3]\n\t"
-        "s_or_b64 %[t], %[t], vcc\n\t"
-        "s_cbranch_scc0 2f\n\t"
-        "s_add_u32 %[st], %[st], 1\n\t"
-        "s_cmp_le_u32 %[st], %[lim]\n\t"
-        "s_cbranch_scc1 1b\n"
-        "2:\n\t"
-        // the lanes that found or claimed their slot add their share
-        "s_andn2_b64 exec, %[c0], %[m0]\n\t"
-        "v_lshl_add_u32 %[r0], %[s0], 3, %[vb]\n\t"
-        "ds_add_f64 %[r0], %[v0]\n\t"
-        "s_andn2_b64 exec, %[c1], %[m1]\n\t"
-        "v_lshl_add_u32 %[r1], %[s1], 3, %[vb]\n\t"
-        "ds_add_f64 %[r1], %[v1]\n\t"
-        "s_andn2_b64 exec, %[c2], %[m2]\n\t"
-        "v_lshl_add_u32 %[r2], %[s2], 3, %[vb]\n\t"
-        "ds_add_f64 %[r2], %[v2]\n\t"
-        "s_andn2_b64 exec, %[c3], %[m3]\n\t"
-        "v_lshl_add_u32 %[r3], %[s3], 3, %[vb]\n\t"
-        "ds_add_f64 %[r3], %[v3]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3),
-          [m0] "+&s"(m0), [m1] "+&s"(m1), [m2] "+&s"(m2), [m3] "+&s"(m3),     // (early clobber: never the registers of act[])
-          [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3),
-          [sv] "=&s"(sv), [t] "=&s"(t), [st] "=&s"(st)
-        : [k0] "v"(k[0]), [k1] "v"(k[1]), [k2] "v"(k[2]), [k3] "v"(k[3]),
-          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
-          [c0] "s"(act[0]), [c1] "s"(act[1]), [c2] "s"(act[2]), [c3] "s"(act[3]),
-          [emp] "v"(kEmpty), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [lim] "n"(kMaxProbe)
-        : "vcc", "scc", "memory");
-    if ((m0 | m1 | m2 | m3) != 0 && (threadIdx.x & 63) == 0) *flag = 1u;    // a lane gave up at the probe limit (wave-uniform test)
-}
-
 // Direct-indexed table for graphs with N <= slots (Cora, Citeseer): the slot IS the node id, so an insert
 // is one plain store of the packed key (every writer stores the same word) and one ds_add_f64 -- no
 // hash, no compare-and-swap, no probing loop -- and SCAN walks N slots instead of a 4x over-provisioned
@@ -730,36 +587,13 @@ __device__ __forceinline__ bool res_add_direct(int* keys, double* vals, u32 node
 // Claim a slot for k without touching its value (same probe sequence as res_add_lds).
 __device__ __forceinline__ bool lds_claim(int* keys, u32 cap, int k) {
     u32 slot = home_lds((u32)k, cap);
-#if GP_ASM_PROBE
     const int seen_a = probe_cas_asm(keys, slot, k);
     return seen_a == kEmpty || seen_a == k;
-#else
-#pragma unroll 1
-    for (u32 step = 1; step <= kMaxProbe; ++step) {
-        int seen = kEmpty;
-        __hip_atomic_compare_exchange_strong(&keys[slot], &seen, k, __ATOMIC_RELAXED,
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (seen == kEmpty || seen == k) return true;
-        slot += step;                               // stays below cap, see home_lds
-    }
-    return false;
-#endif
 }
 // Read-only lookup (no inserts may run concurrently): slot of k, or -1.
 __device__ __forceinline__ int lds_find(const int* keys, u32 cap, int k) {
     u32 slot = home_lds((u32)k, cap);
-#if GP_ASM_PROBE
     return probe_find_asm(keys, slot, k) == k ? (int)slot : -1;
-#else
-#pragma unroll 1
-    for (u32 step = 1; step <= kMaxProbe; ++step) {
-        const int seen = keys[slot];
-        if (seen == k) return (int)slot;
-        if (seen == kEmpty) return -1;
-        slot += step;                               // stays below cap, see home_lds
-    }
-    return -1;
-#endif
 }
 
 __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double v) {
@@ -788,7 +622,8 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
 // control flow: DPP scan); a lane with len == 0 appends nothing.  ONE LDS atomic per call hands out entry indices and edge
 // offsets together; an entry that contains a multiple of 64 edges also records itself in the boundary table (read by
 // levels with more than 64 entries, see edge_stream).
-__device__ __forceinline__ void push_alloc(KP p, Ctl* ctl, LevelCtr* nx, PushEntry* push, u32* bt_g,
+template <class CTL>
+__device__ __forceinline__ void push_alloc(KP p, CTL* ctl, LevelCtr* nx, PushEntry* push, u32* bt_g,
                                            u32 len, u32 start, double share, int lane)
 {
     const u64 M = __ballot(len != 0);
@@ -821,7 +656,7 @@ __device__ __forceinline__ Heavy heavy_view(KP p, Ctl* ctl) {
 __device__ __forceinline__ void heavy_note(Ctl* ctl, const Heavy& h, int k, double val) {
     if (val >= h.thr) {                                                               // ~3 % of the records
         const u32 hi = __hip_atomic_fetch_add(&ctl->n_heavy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (hi < h.cap) { if (GP_HEAVY_STORE) h.keys[hi] = k; } else ctl->heavy_ovf = 1u;
+        if (hi < h.cap) h.keys[hi] = k; else ctl->heavy_ovf = 1u;
     }
 }
 
@@ -1127,10 +962,10 @@ __device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* r
 // The walk is a three-stage software pipeline: while the columns of step s are inserted (f), the column loads of step s+1 and
 // the entry load of step s+2 are in flight.  Every wait of an iteration sits at its top, so the loads issued behind it may
 // be conditional without the compiler's wait counts turning conservative; lanes without an edge load the sentinel word
-// indices[nnz] = -1 (all four column loads of a step are unconditional).  f(col[4], share[4]) is called once per step;
-// col < 0 = no edge.
-template <int BLOCK, class F>
-__device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* push, const u32* bt,
+// indices[nnz] = -1 (all four column loads of a step are unconditional).  f(col[4], share[4], t0) is called once per step;
+// col < 0 = no edge; lane i of window w holds edge number t0 + 64 w + i of the level.
+template <int BLOCK, class CTL, class F>
+__device__ __forceinline__ void edge_stream(KP p, CTL* ctl, const PushEntry* push, const u32* bt,
                                             u32 n_ent, u32 E, bool dry, F f)
 {
     constexpr u32 kWaves = BLOCK / 64;
@@ -1193,6 +1028,7 @@ __device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* pus
     fetch_next(0);                           // t0n = t1n = 0: takes the regular branch
 
     int nc[4] = {-1, -1, -1, -1}; double ns[4] = {0.0, 0.0, 0.0, 0.0};     // columns in flight and their shares
+    u32 nt0 = 0;                                                           // ... and the number of their first edge
     bool have_cols = false;
     // One loop: match the next step's edges to its entries (LDS only), take over the columns of the step before (their loads
     // have been in flight since the previous iteration), issue the next step's column loads and the entry load of the step
@@ -1238,6 +1074,7 @@ __device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* pus
         int cc[4]; double cs[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; cs[w] = ns[w]; }
+        const u32 ct0 = nt0;
 #ifdef GP_DIAG_HEAVY
         if (cc[0] == 0x7FFFFFF0 && cc[1] == 0x7FFFFFF0 && cc[2] == 0x7FFFFFF0 && cc[3] == 0x7FFFFFF0) xs[6] += 1;      // (uses the loaded values: the wait is charged here)
         GP_XS(1); xs[3] += 1;
@@ -1247,9 +1084,10 @@ __device__ __forceinline__ void edge_stream(KP p, Ctl* ctl, const PushEntry* pus
         if (have_ent) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; ns[w] = sh[w]; }
+            nt0 = t0n;
             fetch_next(end);
         }
-        if (had_cols) f(cc, cs);
+        if (had_cols) f(cc, cs, ct0);
         GP_XS(2);
     } while (have_cols);
     GP_XS_FLUSH();
@@ -1263,24 +1101,12 @@ __device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double*
                                              u32 n_ent, u32 E, u32 part, u32 parts, bool dry = false)
 {
     u32* flag = IN_LDS ? &ctl->ovf : &ctl->fail;         // LDS partition overflow is recoverable, an HBM table overflow is not
-    edge_stream<BLOCK>(p, ctl, push, bt, n_ent, E, dry, [&](const int (&v)[4], const double (&sh)[4]) {
-#if GP_ASM_WINDOW && !GP_CHEAP_HASH
+    edge_stream<BLOCK>(p, ctl, push, bt, n_ent, E, dry, [&](const int (&v)[4], const double (&sh)[4], u32) {
         if (IN_LDS && !DIRECT) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) insert_window_asm(lkeys, lvals, cap, flag, v[w], sh[w], parts, part);         // graph.h:98
             return;
         }
-#endif
-#if GP_INSERT4
-        if (IN_LDS && !DIRECT) {
-            u64 act[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                act[w] = __ballot(v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part));
-            insert4_lds(lkeys, lvals, cap, v, sh, act, flag);                                          // graph.h:98
-            return;
-        }
-#endif
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             if (v[w] >= 0 && (parts == 1 || slot_of(hash_b((u32)v[w]), parts) == part))
@@ -1456,7 +1282,7 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
     u32 live_nodes = 0;
     if (p.prune && seg_len >= 2 * K && n_levels >= 1) {
         // (phase_tau already did all of this for the rows whose threshold level was not their last one)
-        const bool early = GP_HEAVY && GP_HEAVY_USE && uni(ctl->tau_early) > 0.0 && !uni(ctl->heavy_ovf);
+        const bool early = uni(ctl->tau_early) > 0.0 && !uni(ctl->heavy_ovf);
         double tau = early ? uni(ctl->tau_early) : 0.0;
         if (early) {
             if (tid == 0) { ctl->n_cand = 0; ctl->ovf = 0; }
@@ -1799,16 +1625,7 @@ __device__ __forceinline__ WgView wg_view(KP p, u32 lds0) {
     return w;
 }
 #define GP_PHASE_NOINLINE static __attribute__((noinline))
-// -DGP_INLINE_HOT=1 (A/B): EXPAND and the dense SCAN inlined into the level loop again (what a call costs: the callee's
-// entry waits for ALL outstanding memory operations of the wave, its prologue re-derives the workgroup's pointers)
-#ifndef GP_INLINE_HOT
-#define GP_INLINE_HOT 0
-#endif
-#if GP_INLINE_HOT
-#define GP_PHASE_HOT static __forceinline__
-#else
 #define GP_PHASE_HOT GP_PHASE_NOINLINE
-#endif
 
 // EXPAND of one level (or one hash partition of it).  MODE 0: LDS hash table, 1: HBM table, 2: direct-indexed LDS table.
 template <int BLOCK, int MODE>
@@ -2028,7 +1845,7 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
     GP_STAMP(t0);
     // one lane per edge, like EXPAND
     edge_stream<BLOCK>(p, ctl, push_cur, w.bt2 + (size_t)cur * p.bt_cap, n_ent, E, false,
-                       [&](const int (&v)[4], const double (&sh)[4]) {
+                       [&](const int (&v)[4], const double (&sh)[4], u32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (v[q] < 0) continue;
@@ -2236,7 +2053,7 @@ __device__ __forceinline__ void gfpush_rows()
         auto give_up = [&]() {
             if (tid == 0) {
                 if (p.retry_list) {
-                    const u64 i = __hip_atomic_fetch_add(&p.counters[kRetryRows], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 i = __hip_atomic_fetch_add(&p.counters[p.retry_counter], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     p.retry_list[i] = (u32)row;
                 } else {
                     stat_add_final(ctl, sFailed, 1);
@@ -2321,11 +2138,9 @@ __device__ __forceinline__ void gfpush_rows()
             // what the LDS table is planned for: the estimate of DISTINCT targets (Ctl::ratio_q); a level that outgrows it overflows
             // its table and is split like any partition that does not fit
             u64 need_t = need;
-#if GP_RATIO_EST
             // (only where it changes the plan: at >= 0.8 targets per edge -- the power-law shapes -- the estimate buys no pass and an
             //  overflow now and then costs one: MAG -0.6 % when it was applied everywhere)
             if (lvl < 16) { const u32 rq = uni(ctl->ratio_q[lvl]); if (rq && rq <= 820u) need_t = min(need, (((u64)e_cur * rq) >> 10) + 64u); }
-#endif
             // placement of the level's residue table
             bool in_lds = !p.force_global;
             u32 parts = 1, cap = 0;
@@ -2334,23 +2149,6 @@ __device__ __forceinline__ void gfpush_rows()
             if (direct) {
                 cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
             } else if (in_lds) {
-#if GP_EVEN_WALK
-                // SCAN hands every wave a range of whole 256-slot steps: a capacity that is a multiple of (waves x 256) gives every
-                // wave the SAME number of steps (6 378 slots over 12 waves were 3+3+3+3+3+3+3+3+1+0+0+0 steps; 6 144 are 2 each)
-                constexpr u32 gran = (BLOCK / 64) * 256u;
-                const u32 Ce = C >= 2u * gran ? (C / gran) * gran : C;           // the largest even-walk capacity
-                const u32 want = (u32)GP_CAP_MULT * (u32)min(need, (u64)C);
-                if (need * GP_LOAD_DEN <= (u64)Ce * GP_LOAD_NUM) {
-                    cap = want <= kMinCap ? kMinCap : min(Ce, ((want + gran - 1u) / gran) * gran);
-                    if (Ce == C) cap = min(C, max(kMinCap, (want + 3u) & ~3u));
-                } else if (need > (u64)kMaxParts * Ce) {
-                    in_lds = false;                      // more than kMaxParts partitions: the HBM table
-                } else {
-                    parts = ((u32)need * GP_LOAD_DEN + Ce * GP_LOAD_NUM - 1u) / (Ce * GP_LOAD_NUM);     // need <= 64 C < 2^21: 32-bit arithmetic
-                    cap = Ce;
-                    if (parts > kMaxParts) in_lds = false;
-                }
-#else
                 if (need_t * GP_LOAD_DEN <= (u64)C * GP_LOAD_NUM) {
                     cap = min(C, max(kMinCap, ((u32)GP_CAP_MULT * (u32)need_t + 3u) & ~3u));
                 } else if (need_t > (u64)kMaxParts * C) {
@@ -2362,7 +2160,6 @@ __device__ __forceinline__ void gfpush_rows()
                     cap = C;
                     if (parts > kMaxParts) in_lds = false;
                 }
-#endif
             }
             const u32 snap_log = log_pos;                      // first log record of this level
 #ifdef GP_DIAG
@@ -2402,7 +2199,7 @@ __device__ __forceinline__ void gfpush_rows()
             }
             // a small level: one wave does it, the others park at one barrier (phase_solo_level)
             bool solo_done = false;
-            if (GP_SOLO && in_lds && !direct && parts == 1 && !lvl_seedrow && !use_buckets && p.solo &&
+            if (in_lds && !direct && parts == 1 && !lvl_seedrow && !use_buckets && p.solo &&
                 e_cur <= kSoloEdges && n_ent_cur >= 1u && n_ent_cur <= kSoloEntries && !uni(ctl->fail) &&
                 solo_caps && (u64)log_pos + kSoloEdges + 2u <= p.log_cap) {
                 GP_STAMP(t0);
@@ -2488,20 +2285,16 @@ __device__ __forceinline__ void gfpush_rows()
             {
                 const u32 lvl_len = uni(nx->n_rec);                      // read after the level's last barrier (see LevelCtr::n_rec)
                 log_pos += lvl_len;
-#if GP_RATIO_EST
                 if (tid == 0 && lvl < 16 && e_cur > 0u) {                // lvl_len = the level's distinct targets
                     const u32 obs = min(1024u, (u32)(1178.0f * (float)lvl_len * __frcp_rn((float)e_cur)) + 2u);    // 1.15 x 1024 x nodes / edges, rounded up (fp32: a 64-bit division here is ~150 instructions per level)
                     const u32 old_q = ctl->ratio_q[lvl];
                     ctl->ratio_q[lvl] = max(obs, old_q - (old_q >> 3));
                 }
-#endif
                 n_levels = lvl + 1;
                 // first level with >= 2K records (early levels hold the LARGEST records: a stronger bound than the biggest level)
                 if (c > 0.0 && seg_len < 2u * (u32)p.K && lvl_len > seg_len) {
                     seg_begin = snap_log; seg_len = lvl_len;
-#if GP_HEAVY
                     if (seg_len >= 2u * (u32)p.K && p.prune && do_push && !uni(ctl->fail)) phase_tau<BLOCK>(lds0, seg_begin, seg_len, (u32)(L + 1));
-#endif
                 }
             }
             if (!do_push || uni(ctl->fail)) break;

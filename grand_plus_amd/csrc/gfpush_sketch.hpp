@@ -1,0 +1,847 @@
+// gfpush_sketch.hpp -- the round-4 GFPush kernel for gfx950: exact residues only where they can matter.
+//
+// Same contract as gfpush_kernels.hpp (reference precompute/graph.h:73-126, one persistent workgroup per row), different
+// structure.  Two facts about the shipped recipes (rmax >= 5e-6 on large graphs; tools/sim/*.cpp measured them on the
+// MAG shape) carry it:
+//
+//   * Only ~8 % of a level's frontier nodes pass the push test r >= rmax*deg (graph.h:94); the other 92 % only
+//     deposit coef*r into the reserve (graph.h:90) and are dropped.  And the reserve is LINEAR in the pushed shares:
+//     reserve[v] = sum over levels and in-edges of coef[l] * share(u).  So a pushed edge (u -> v) needs an EXACT fp64
+//     accumulator for v only if v may push; everything else is one 12-byte log record per edge.
+//   * Whether v may push is decided by a KEYLESS upper bound: the level SKETCH U[h(v)] += ceil(share * 2^31) -- one
+//     fire-and-forget ds_add_u32 per edge, no key, no compare-and-swap, no probing, 4 bytes per cell instead of 12 per
+//     slot.  Collisions only ever ADD, so U[h(v)] * 2^-31 >= r(v), and v can push only if its cell reaches
+//     rmax * min(deg, deg_sat) (the degree rides in the packed column word).  On the MAG shape a 8 192-cell sketch lets
+//     23 % of the edges through to the exact table (the true pushers own 16 %); the peak levels -- 7 400 edges, three
+//     hash-partition passes at 52 KB in the round-3 kernel -- take ONE stream over the CSR plus one over the level's log.
+//
+// Per level l = 1..L of a row (graph.h:83-110):
+//   STREAM  edge_stream over the push list (one lane per edge, gfpush_kernels.hpp): the packed column word and the
+//           pusher's share go to the reserve LOG at position (level base + edge number) -- no allocation, fully
+//           coalesced -- and ceil(share * 2^31) into the level sketch U.  Small levels skip U and insert straight into
+//           the exact table.
+//   FILTER  re-reads the level's log segment (L2-hot, next group of 256 records in flight while one is processed), looks
+//           every edge's cell up and inserts the edges whose target may push into the exact table X (insert_window_asm:
+//           the round-3 LDS hash insert, fp64 atomic add).  X is planned for <= 0.6 load from the candidates per edge the
+//           workgroup's earlier rows had at that level; more than that is walked in hash partitions.
+//   SCAN    drains X: exact push test with the packed degree, indptr lookup for the nodes that pass, dangling rule
+//           (graph.h:91-93), fp64 division, next push list (push_alloc).  A tenth of the round-3 SCAN's items and no log
+//           append: the records were written per edge by STREAM.
+// TOP-K (graph.h:111-126), with the level tables dead and all of the LDS free:
+//   R[h(v)] += ceil(coef[level] * share * scale) over the whole log (one pipelined sweep) is an upper bound on every
+//   node's reserve, so the K largest totals live in heavy cells.  The cell value t_c of rank ~2K is read off a histogram
+//   of R, a second sweep sums (exactly, fp64, keyed table) the records whose cell reaches t_c, and if the K-th largest
+//   exact total tau satisfies tau*scale >= t_c no unswept node can beat it: done (95 % of MAG rows; ~200 nodes tabled
+//   instead of the 12 500 of the support).  Otherwise tau is a proven lower bound and one more sweep with t_c = tau*scale
+//   is complete by construction; when its nodes outgrow the table it runs in hash partitions, each partition's K best
+//   merged into a running list (flat rows: thousands of equal totals).
+//
+// What is left over -- a workspace bound, more than 64 partitions, more than 256 near-ties, totals outside [2^-63, 2) --
+// sends the row to the retry list, and the general kernel (gfpush_retry_kernel) runs it.  Not counted here: frontier /
+// support sizes (no structure sees distinct targets any more); `exact_stats` selects the general kernel.
+#pragma once
+
+#include "gfpush_kernels.hpp"
+
+#ifndef GP_DIAG      // the diagnostic build instruments the general kernel only
+
+namespace gp {
+
+constexpr int kSkMaxCoef = 40;            // levels the control block has room for (longer recipes: general kernel)
+constexpr u32 kSkTie     = 256;           // the select ranks at most this many candidates by comparison
+constexpr u32 kSkMulA    = 0x9E3779B1u;   // sketch hash: cell = top bits of key * kSkMulA
+
+struct CtlS {
+    long long row;
+    LevelCtr lc[2];                       // what SCAN of level l produces for level l+1 lives in lc[l & 1] (n_rec: nodes it drained)
+    u32 ovf;                              // an exact table / aggregation overflowed
+    u32 fail;                             // the row leaves for the retry list
+    u32 n_sel, n_tie;                     // select: entries above the K-th bin / inside it
+    u32 tk_bin, tk_above, tk_count, tk_total;
+    u32 tk_sub, tk_t, tk_wide, tk_pad;
+    u64 kth_bits;                         // smallest selected value (bit pattern)
+    u32 bcnt[64];                         // select: binade counters
+    u64 st[8], st_row[8];                 // statistics: workgroup totals / the row in flight
+    double coef[kSkMaxCoef];
+    u32 seg_off[kSkMaxCoef + 2];          // first log record of every level; [n_levels] = end of the log
+    u32 cand_q[kSkMaxCoef];               // per level: exact-table nodes per pushed edge of this workgroup's earlier rows (x 1.25, in 1/1024)
+#ifdef GP_SK_TIMING
+    u64 tacc[16]; u64 tlast;              // -DGP_SK_TIMING: 100 MHz ticks thread 0 spent per phase (flushed to the diag_sub counters)
+    u64 tacc2[14]; u64 tlast2;            // ... and inside FILTER / SCAN / STREAM (tools/sk_phases.py)
+#endif
+};
+// -DGP_SK_TIMING (tools/sk_phases.py): thread 0 stamps the phases with the constant 100 MHz clock.  [0] row prologue + level 0,
+// [1] STREAM of small levels (exact inserts), [2] STREAM of sketch levels, [3] STREAM of the last level, [4] FILTER, [5] SCAN,
+// [6] rest of the level loop, [7] TOP-K: R + threshold, [8] TOP-K sweeps, [9] select, [10] output + row end, [11] filter calls,
+// [12] scan calls, [13] small levels, [14] sketch levels, [15] rows.  Barriers are charged to the phase in front of them.
+#ifdef GP_SK_TIMING
+#define SKT_BEGIN(ctl) do { if (threadIdx.x == 0) (ctl)->tlast = wall_clock64(); } while (0)
+#define SKT(ctl, i) do { if (threadIdx.x == 0) { const u64 n_ = wall_clock64(); (ctl)->tacc[i] += n_ - (ctl)->tlast; (ctl)->tlast = n_; } } while (0)
+#define SKT_COUNT(ctl, i, n) do { if (threadIdx.x == 0) (ctl)->tacc[i] += (n); } while (0)
+#define SKT2_BEGIN(ctl) do { if (threadIdx.x == 0) (ctl)->tlast2 = wall_clock64(); } while (0)
+#define SKT2(ctl, i) do { if (threadIdx.x == 0) { const u64 n_ = wall_clock64(); (ctl)->tacc2[i] += n_ - (ctl)->tlast2; (ctl)->tlast2 = n_; } } while (0)
+#else
+#define SKT_BEGIN(ctl) do { } while (0)
+#define SKT(ctl, i) do { } while (0)
+#define SKT_COUNT(ctl, i, n) do { } while (0)
+#define SKT2_BEGIN(ctl) do { } while (0)
+#define SKT2(ctl, i) do { } while (0)
+#endif
+static_assert(sizeof(CtlS) <= (size_t)kCtlStruct, "the control block must fit its LDS reservation");
+enum StatS { zPush = 0, zEdges, zDeg, zFilled, zLevels, zFailed, zCand, zSweep2, zNumStats };
+__device__ __forceinline__ void zstat(CtlS* ctl, int which, u64 n) {
+    __hip_atomic_fetch_add(&ctl->st_row[which], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LDS of a workgroup: CtlS + the per-wave flag bytes (kCtlBytes, as in the general kernel) | U u32[MU] | X values f64[CX] |
+// X keys i32[CX].  TOP-K re-uses all of it behind the control block as
+// { R u32[MR] | aggregation values f64[CA] | keys i32[CA] | tie Cand[256] | sel Cand[K] }.
+struct SkView {
+    CtlS* ctl; u32* U; double* xvals; int* xkeys; u32 MU, CX, shU;
+    PushEntry* push2; u32* bt2; int* log_key; double* log_val;
+    u32 lds_u;                            // byte offset of U inside LDS
+};
+__device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
+    SkView w;
+    w.MU = 1u << p.sk_lg_mu; w.CX = p.sk_cx;
+    w.shU = 32u - p.sk_lg_mu;
+    w.ctl = lds_at<CtlS>(lds0);
+    w.lds_u = lds0 + (u32)kCtlBytes;
+    w.U = lds_at<u32>(w.lds_u);
+    w.xvals = lds_at<double>(w.lds_u + 4u * w.MU);
+    w.xkeys = lds_at<int>(w.lds_u + 4u * w.MU + 8u * w.CX);
+    const size_t wg = blockIdx.x;
+    w.push2   = p.push + wg * 2 * p.push_cap;
+    w.bt2     = p.bt + wg * 2 * p.bt_cap;
+    w.log_key = p.log_key + wg * p.log_cap;
+    w.log_val = p.log_val + wg * p.log_cap;
+    return w;
+}
+__device__ __forceinline__ void lds_add_u32(u32* cell, u32 v) {
+    __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// fixed-point image of a non-negative fp64 quantity, rounded UP: sums of these bound the fp64 sums from above
+__device__ __forceinline__ u32 fx_up(double x) { return (u32)__builtin_ceil(x); }
+
+// Walks log records [0, n) in groups of 256 (four 64-lane windows), groups dealt to the waves round robin; f(key[4], val[4],
+// first record of the group) runs while the NEXT group's eight loads are in flight.  Lanes past n get key -1.
+template <int BLOCK, class F>
+__device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 n, F f)
+{
+    constexpr u32 kStride = (BLOCK / 64) * 256u;
+    const u32 lane = threadIdx.x & 63u;
+    u32 g = wave_id() * 256u;
+    if (g >= n) return;
+    int kn[4]; double sn[4];
+    auto load = [&](u32 g0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 i = g0 + 64u * (u32)q + lane;
+            kn[q] = -1; sn[q] = 0.0;
+            if (i < n) { kn[q] = lk[i]; sn[q] = lv[i]; }
+        }
+    };
+    load(g);
+    for (;;) {
+        int k[4]; double s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { k[q] = kn[q]; s[q] = sn[q]; }
+        const u32 cur = g;
+        g += kStride;
+        const bool more = g < n;                                      // wave-uniform
+        if (more) load(g);
+        f(k, s, cur);
+        if (!more) break;
+    }
+}
+
+// ---------------------------------------------------------------- STREAM
+// MODE 0: log + level sketch U.   MODE 1: log + exact insert into X (small levels).   MODE 2: log only (last level).
+template <int BLOCK, int MODE>
+__device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, u32 capx,
+                                                  u32 has_dang, double dang, int seed_key)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); capx = uni(capx);
+    has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key);
+    const SkView w = sk_view(p, lds0);
+    const u32 lane = threadIdx.x & 63u;
+    int* lk = w.log_key + seg_base; double* lv = w.log_val + seg_base;
+    edge_stream<BLOCK>(p, w.ctl, w.push2 + (size_t)cur * p.push_cap, w.bt2 + (size_t)cur * p.bt_cap, n_ent, E, false,
+                       [&](const int (&v)[4], const double (&sh)[4], u32 t0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (v[q] >= 0) {
+                const u32 li = t0 + 64u * (u32)q + lane;                              // the edge's number inside the level
+                lk[li] = v[q]; lv[li] = sh[q];                                        // graph.h:98 -> one log record per edge
+                if (MODE == 0) lds_add_u32(&w.U[((u32)v[q] * kSkMulA) >> w.shU], fx_up(sh[q] * 2147483648.0));
+            }
+            if (MODE == 1) insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q], 1u, 0u);
+        }
+    });
+    if (threadIdx.x == 0 && has_dang) {                                               // graph.h:92: the seed gets the dangling mass
+        lk[E] = seed_key; lv[E] = dang;
+        if (MODE == 0) lds_add_u32(&w.U[((u32)seed_key * kSkMulA) >> w.shU], fx_up(dang * 2147483648.0));
+        if (MODE == 1 && !res_add_lds(w.xkeys, w.xvals, capx, seed_key, dang)) w.ctl->ovf = 1;
+    }
+}
+
+// ---------------------------------------------------------------- FILTER
+// The level's log segment [seg_base, seg_base + n): edges whose target MAY push (its sketch cell reaches rmax * packed degree)
+// go into the exact table.  use_u == 0: every edge does (partition walk of a small level whose table overflowed).
+// parts > 1: only targets of hash partition `part`.
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n, u32 capx, u32 use_u, u32 parts, u32 part)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); seg_base = uni(seg_base); n = uni(n); capx = uni(capx); use_u = uni(use_u); parts = uni(parts); part = uni(part);
+    const SkView w = sk_view(p, lds0);
+    const float thr = p.sk_thr_f;
+    u32 n_cand = 0;
+    SKT2(w.ctl, 0);
+    log_groups<BLOCK>(w.log_key + seg_base, w.log_val + seg_base, n, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (g0 + 64u * (u32)q >= n) break;                                        // wave-uniform
+            bool cand = k[q] >= 0;
+            if (use_u && cand) {
+                const u32 cell = w.U[((u32)k[q] * kSkMulA) >> w.shU];
+                const u32 dq = (u32)k[q] >> p.deg_shift;                              // min(deg, deg_sat); 0: dangling, always exact
+                cand = (float)cell >= (float)dq * thr;                                // thr = rmax * 2^31 * (1 - 2^-10), rounded down
+            }
+            n_cand += (u32)__popcll(__ballot(cand));
+            insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, cand ? k[q] : -1, s[q], parts, part);   // graph.h:98
+        }
+    });
+    if ((threadIdx.x & 63u) == 0 && n_cand && part == 0u) zstat(w.ctl, zCand, n_cand);
+    SKT2(w.ctl, 1);
+}
+
+// ---------------------------------------------------------------- SCAN
+// Drains the exact table (cap slots in use, C allocated; C % 4 == 0, slots in [cap, C) are empty): compact, cheap push test
+// on the packed degree, compact again, then indptr lookup / dangling rule / division / push list for the nodes that remain.
+// clear_u: the level sketch is dead (this is the level's last partition) -- zero it for the next level.
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, u32 clear_u)
+{
+    typedef int    i4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef u32    u4 __attribute__((ext_vector_type(4)));
+    KP p = kparams();
+    lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); clear_u = uni(clear_u);
+    const SkView w = sk_view(p, lds0);
+    CtlS* ctl = w.ctl;
+    int* lkeys = w.xkeys; double* lvals = w.xvals;
+    const u32 C = w.CX;
+    LevelCtr* nx = &ctl->lc[nx_sel];
+    PushEntry* push = w.push2 + (size_t)nxt_sel * p.push_cap;
+    u32* bt_g = w.bt2 + (size_t)nxt_sel * p.bt_cap;
+    const int tid = threadIdx.x, lane = tid & 63;
+    SKT2(ctl, 4);
+    if (clear_u) {
+        const u4 z = {0u, 0u, 0u, 0u};
+        for (u32 i = 4u * (u32)tid; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
+    }
+    constexpr u32 kWaves = BLOCK / 64;
+    const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
+    const u32 wb = wave_id() * range;
+    u32 tot = 0;
+    for (u32 sub = wb; sub < wb + range && sub < cap; sub += 256u) {
+        const u32 s0 = sub + 4u * (u32)lane;
+        i4 kk = {kEmpty, kEmpty, kEmpty, kEmpty};
+        if (s0 < C) kk = *(const i4*)&lkeys[s0];
+        const bool o0 = kk.x != kEmpty, o1 = kk.y != kEmpty, o2 = kk.z != kEmpty, o3 = kk.w != kEmpty;
+        const u64 m0 = __ballot(o0), m1 = __ballot(o1), m2 = __ballot(o2), m3 = __ballot(o3);
+        const u32 c0 = (u32)__popcll(m0), c1 = (u32)__popcll(m1), c2 = (u32)__popcll(m2), c3 = (u32)__popcll(m3);
+        if (c0 + c1 + c2 + c3 == 0) continue;                       // wave-uniform
+        if (o0 | o1 | o2 | o3) {
+            const d2 ra = *(const d2*)&lvals[s0], rb = *(const d2*)&lvals[s0 + 2];
+            const i4 ke = {kEmpty, kEmpty, kEmpty, kEmpty};
+            const d2 z = {0.0, 0.0};
+            *(i4*)&lkeys[s0] = ke; *(d2*)&lvals[s0] = z; *(d2*)&lvals[s0 + 2] = z;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);                // clears stay ahead of the staging stores
+            const u32 q0 = wb + tot;                                // [wb, wb + tot) lies inside the slots drained so far
+            if (o0) { const u32 q = q0 + lane_prefix(m0);                lkeys[q] = kk.x; lvals[q] = ra.x; }
+            if (o1) { const u32 q = q0 + c0 + lane_prefix(m1);           lkeys[q] = kk.y; lvals[q] = ra.y; }
+            if (o2) { const u32 q = q0 + c0 + c1 + lane_prefix(m2);      lkeys[q] = kk.z; lvals[q] = rb.x; }
+            if (o3) { const u32 q = q0 + c0 + c1 + c2 + lane_prefix(m3); lkeys[q] = kk.w; lvals[q] = rb.y; }
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        tot += c0 + c1 + c2 + c3;
+    }
+    u32 st_push = 0, st_edges = 0, st_deg = 0;
+    SKT2(ctl, 5);
+    if (tot != 0) {
+        // the cheap half of the push test: the exact degree is in the key unless the field is saturated (graph.h:94)
+        u32 ncand = 0;
+        for (u32 j = 0; j < tot; j += 128u) {
+            int k[2]; double r[2]; bool cnd[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const u32 idx = j + 64u * (u32)v + (u32)lane;
+                k[v] = kEmpty; r[v] = 0.0; cnd[v] = false;
+                if (idx < tot) {
+                    k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
+                    lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
+                    const u32 dq = (u32)k[v] >> p.deg_shift;
+                    cnd[v] = dq == 0u || r[v] >= p.rmax * (double)dq;
+                }
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);                // reads and clears stay ahead of the list stores
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const u64 m = __ballot(cnd[v]);
+                if (cnd[v]) { const u32 q = wb + ncand + lane_prefix(m); lkeys[q] = k[v]; lvals[q] = r[v]; }
+                ncand += (u32)__popcll(m);                          // <= nodes consumed so far: stays inside cleared slots
+            }
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        SKT2(ctl, 6);
+        for (u32 j = 0; j < ncand; j += 128u) {
+            int k[2]; double r[2]; bool want[2]; int ds[2], de[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const u32 idx = j + 64u * (u32)v + (u32)lane;
+                want[v] = idx < ncand; k[v] = kEmpty; r[v] = 0.0; ds[v] = 0; de[v] = 0;
+                if (want[v]) {
+                    k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
+                    lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
+                    const int node = (int)((u32)k[v] & p.node_mask);
+                    ds[v] = p.indptr[node]; de[v] = p.indptr[node + 1]; ++st_deg;           // graph.h:43-45
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                if (__ballot(want[v]) == 0) continue;                                     // wave-uniform
+                double share = 0.0; u32 len = 0;
+                if (want[v]) {
+                    const u32 deg = (u32)(de[v] - ds[v]);
+                    if (deg == 0) {                                                       // graph.h:91-93
+                        __hip_atomic_fetch_add(&nx->dangling, r[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else if (r[v] >= p.rmax * (double)deg) {                            // graph.h:94
+                        ++st_push; st_edges += deg;
+                        const double sh = r[v] / (double)deg;                             // graph.h:95
+                        if (sh != 0.0) { share = sh; len = deg; }
+                    }
+                }
+                push_alloc(p, ctl, nx, push, bt_g, len, (u32)ds[v], share, lane);
+            }
+        }
+        SKT2(ctl, 7);
+        st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
+        if (lane == 0) {
+            __hip_atomic_fetch_add(&nx->n_rec, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // nodes the exact table held
+            if (st_deg) zstat(ctl, zDeg, st_deg);
+            if (st_push) { zstat(ctl, zPush, st_push); zstat(ctl, zEdges, st_edges); }
+        }
+    }
+    SKT2(ctl, 8);
+}
+
+// ---------------------------------------------------------------- TOP-K
+struct SkTop {                             // TOP-K's carving of the LDS behind the control block
+    u32* R; u32 MR, shR; double* avals; int* akeys; u32 CA; Cand* tie; Cand* sel; u32* fine;
+};
+__device__ __forceinline__ SkTop sk_top(KP p, const SkView& w) {
+    SkTop t;
+    t.MR = 1u << p.sk_lg_mr; t.shR = 32u - p.sk_lg_mr;
+    t.R = lds_at<u32>(w.lds_u);
+    const u32 region_bytes = 4u * w.MU + 12u * w.CX - 4u * t.MR;
+    t.CA = ((region_bytes - 16u * (kSkTie + (u32)p.K)) / 12u) & ~3u;
+    const u32 a0 = w.lds_u + 4u * t.MR;
+    t.avals = lds_at<double>(a0);
+    t.akeys = lds_at<int>(a0 + 8u * t.CA);
+    t.tie = lds_at<Cand>(a0 + 12u * t.CA);
+    t.sel = t.tie + kSkTie;
+    t.fine = (u32*)((unsigned char*)w.ctl + kCtlStruct);                              // 1 024 words of flag bytes, idle in TOP-K
+    return t;
+}
+// coef[level] of the records of one 64-lane window starting at record ws; `l` = the wave's level cursor (windows arrive in
+// increasing order).  Windows that straddle a level boundary -- the first levels hold a handful of records -- look it up per lane.
+__device__ __forceinline__ double sk_window_coef(const CtlS* ctl, int n_levels, u32 ws, u32 lane, int& l)
+{
+    while (l + 1 < n_levels && ws >= uni(ctl->seg_off[l + 1])) ++l;
+    double c = uni(ctl->coef[l]);
+    if (l + 1 < n_levels && ws + 64u > uni(ctl->seg_off[l + 1])) {
+        int ll = l;
+        const u32 idx = ws + lane;
+        while (ll + 1 < n_levels && idx >= ctl->seg_off[ll + 1]) ++ll;
+        c = ctl->coef[ll];
+    }
+    return c;
+}
+
+// Select the K largest (value desc, column asc) positive totals of the aggregation table into sel[0 .. need) (graph.h:111-121)
+// and note the smallest of them in ctl->kth_bits.  Returns need = min(K, positive totals); 0xFFFFFFFF: the row must leave
+// (more than kSkTie near-ties, or a total outside [2^-63, 2)).  Every thread of the workgroup calls this.
+template <int BLOCK>
+__device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = wave_id(), K = (u32)p.K, CA = t.CA;
+    const int* akeys = t.akeys; const double* avals = t.avals;
+    for (u32 i = tid; i < CA; i += BLOCK) {
+        if (akeys[i] != kEmpty) {
+            const double v = avals[i];
+            if (v > 0.0) {
+                const int e = 1023 - (int)((u64)__double_as_longlong(v) >> 52);
+                if ((u32)e < 64u) lds_add_u32(&ctl->bcnt[e], 1u); else ctl->tk_wide = 1u;
+            }
+        }
+    }
+    GP_SYNC();
+    if (uni(ctl->tk_wide)) return 0xFFFFFFFFu;
+    if (wave == 0) {                                                                  // lane = binade, 0 holds the largest values
+        const u32 cn = ctl->bcnt[lane];
+        const u32 incl = wave_incl_scan_dpp(cn);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 want = min(K, total);
+        const u64 mk = __ballot(incl >= want && want != 0u);
+        const int bl = mk ? __ffsll((long long)mk) - 1 : 63;
+        if (lane == bl) { ctl->tk_bin = (u32)bl; ctl->tk_above = incl - cn; ctl->tk_count = cn; ctl->tk_total = total; ctl->tk_sub = 0xFFFFFFFFu; }
+    }
+    GP_SYNC();
+    const u32 total = uni(ctl->tk_total), b_sel = uni(ctl->tk_bin);
+    u32 above = uni(ctl->tk_above), cnt_b = uni(ctl->tk_count);
+    const u32 need = min(K, total);
+    GP_SYNC();
+    if (need == 0) return 0;
+    if (above + cnt_b > need && cnt_b > kSkTie) {
+        // the binade of the K-th value is crowded: split it by the next 8 mantissa bits
+        for (u32 i = tid; i < 256u; i += BLOCK) t.fine[i] = 0;
+        GP_SYNC();
+        for (u32 i = tid; i < CA; i += BLOCK) {
+            if (akeys[i] != kEmpty) {
+                const u64 bits = (u64)__double_as_longlong(avals[i]);
+                if (avals[i] > 0.0 && 1023u - (u32)(bits >> 52) == b_sel) lds_add_u32(&t.fine[(u32)(bits >> 44) & 255u], 1u);
+            }
+        }
+        GP_SYNC();
+        if (wave == 0) {                                                              // lane j owns sub-bins [4 j, 4 j + 4)
+            u32 cnt[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cnt[j] = t.fine[4 * lane + j]; sum += cnt[j]; }
+            const u32 suf = wave_suffix_scan(sum, lane) + above;                      // entries at or above sub-bin 4 * lane
+            const u64 m = __ballot(suf >= need);
+            const int cl = 63 - __builtin_clzll(m | 1ull);
+            if (lane == cl) {
+                u32 acc = suf - sum; int js = 0;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) { if (acc + cnt[j] >= need) { js = j; break; } acc += cnt[j]; }
+                ctl->tk_sub = 4u * (u32)lane + (u32)js; ctl->tk_above = acc; ctl->tk_count = cnt[js];
+            }
+        }
+        GP_SYNC();
+        above = uni(ctl->tk_above); cnt_b = uni(ctl->tk_count);
+        if (above + cnt_b > need && cnt_b > kSkTie) return 0xFFFFFFFFu;               // > 256 near-ties
+    }
+    const u32 s_sel = uni(ctl->tk_sub);
+    // collect: strictly above the K-th bin -> sel; inside it -> tie (all of it goes to sel when it fits exactly)
+    const bool take_all = above + cnt_b <= need;
+    for (u32 base = 0; base < CA; base += BLOCK) {
+        const u32 i = base + (u32)tid;
+        bool is_sel = false, is_t = false;
+        Cand cd; cd.bits = 0; cd.key = 0; cd.pad = 0;
+        if (i < CA && akeys[i] != kEmpty && avals[i] > 0.0) {
+            cd.bits = (u64)__double_as_longlong(avals[i]); cd.key = akeys[i];         // (the PACKED key: a merged entry goes back into a table)
+            const u32 e = 1023u - (u32)(cd.bits >> 52), sb = (u32)(cd.bits >> 44) & 255u;
+            const bool in_bin = e == b_sel && (s_sel == 0xFFFFFFFFu || sb == s_sel);
+            const bool over = e < b_sel || (e == b_sel && s_sel != 0xFFFFFFFFu && sb > s_sel);
+            is_sel = over || (in_bin && take_all); is_t = in_bin && !take_all;
+        }
+        const u32 si = wave_alloc1(&ctl->n_sel, is_sel, lane);
+        if (is_sel) t.sel[si] = cd;
+        const u32 ti = wave_alloc1(&ctl->n_tie, is_t, lane);
+        if (is_t) t.tie[ti] = cd;
+    }
+    GP_SYNC();
+    if (!take_all) {
+        const u32 nt = uni(ctl->n_tie), n0 = uni(ctl->n_sel), want = need - n0;        // nt == cnt_b <= kSkTie
+        // ties inside the bin are ordered like the output: value desc, then NODE id asc (the packed key's low bits)
+        for (u32 i = tid; i < nt; i += BLOCK) {
+            Cand mine = t.tie[i];
+            const int mk = (int)((u32)mine.key & p.node_mask);
+            u32 rank = 0;
+            for (u32 j = 0; j < nt; ++j) {
+                const Cand o = t.tie[j];
+                const int ok = (int)((u32)o.key & p.node_mask);
+                rank += (o.bits > mine.bits || (o.bits == mine.bits && ok < mk)) ? 1u : 0u;
+            }
+            if (rank < want) t.sel[n0 + rank] = mine;
+        }
+        GP_SYNC();
+    }
+    if ((u32)tid < need) __hip_atomic_fetch_min(&ctl->kth_bits, t.sel[tid].bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    GP_SYNC();
+    return need;
+}
+
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi, int seed, int n_levels, u32 n_log)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); row_lo = uni(row_lo); row_hi = uni(row_hi); seed = uni(seed); n_levels = uni(n_levels); n_log = uni(n_log);
+    const SkView w = sk_view(p, lds0);
+    CtlS* ctl = w.ctl;
+    const SkTop t = sk_top(p, w);
+    const long long row = (long long)(((u64)row_hi << 32) | row_lo);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = wave_id();
+    const u32 K = (u32)p.K;
+    typedef u32 u4 __attribute__((ext_vector_type(4)));
+
+    // ---- R: the reserve of every node, bounded from above cell by cell (graph.h:90 / :109 summed over the whole log)
+    {
+        const u4 z = {0u, 0u, 0u, 0u};
+        for (u32 i = 4u * (u32)tid; i < t.MR; i += 4u * BLOCK) *(u4*)&t.R[i] = z;
+    }
+    for (u32 i = tid; i < 512u; i += BLOCK) t.fine[i] = 0;
+    if (tid == 0) { ctl->ovf = 0; ctl->tk_t = 1u; }
+    GP_SYNC();
+    {
+        int l = 0;
+        log_groups<BLOCK>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 ws = g0 + 64u * (u32)q;
+                if (ws >= n_log) break;                                               // wave-uniform
+                const double c = sk_window_coef(ctl, n_levels, ws, (u32)lane, l) * p.sk_rscale;
+                if (k[q] >= 0) {
+                    const u32 add = fx_up(s[q] * c);
+                    if (add) lds_add_u32(&t.R[((u32)k[q] * kSkMulA) >> t.shR], add);
+                }
+            }
+        });
+    }
+    GP_SYNC();
+    // ---- t_c: the cell value of rank ~ target, off a histogram over (binade, top 4 mantissa bits) of the cells
+    for (u32 i = tid; i < t.MR; i += BLOCK) {
+        const u32 cv = t.R[i];
+        if (cv) {
+            const u32 fb = __float_as_uint((float)cv);                                // >= 1.0f: exponent 127 .. 159
+            lds_add_u32(&t.fine[min(511u, (fb >> 19) - (127u << 4))], 1u);
+        }
+    }
+    GP_SYNC();
+    if (wave == 0) {                                                                  // lane j owns bins [8 j, 8 j + 8)
+        u32 cnt[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cnt[j] = t.fine[8 * lane + j]; sum += cnt[j]; }
+        const u32 suf = wave_suffix_scan(sum, lane);                                  // cells in bins >= 8 * lane
+        const u64 m = __ballot(suf >= p.sk_target);
+        if (m != 0) {
+            const int cl = 63 - __builtin_clzll(m);                                   // highest chunk whose suffix reaches the target
+            if (lane == cl) {
+                u32 acc = suf - sum; int js = 0;
+#pragma unroll
+                for (int j = 7; j >= 0; --j) { acc += cnt[j]; if (acc >= p.sk_target) { js = j; break; } }
+                const u32 bin = 8u * (u32)lane + (u32)js, e = bin >> 4, mt = 16u + (bin & 15u);
+                const u32 edge = e >= 4u ? mt << (e - 4u) : mt >> (4u - e);           // lower edge of the bin (rounded down)
+                ctl->tk_t = max(edge, 1u);
+            }
+        }
+    }
+    GP_SYNC();
+    SKT(ctl, 7);
+    u32 t_c = uni(ctl->tk_t);
+    u32 need = 0;
+    bool last = false;                                                                // t_c is a proven bound: what this round selects is final
+    for (int round = 0; ; ++round) {
+        // One round = every node whose cell reaches t_c, tabled exactly and the K best selected; in P hash partitions when
+        // they outgrow the table, each partition's K best merged with the running list (it goes back into the table).
+        u32 P = 1;
+        for (;;) {
+            bool ovf = false;
+            for (u32 part = 0; part < P; ++part) {
+                const u32 n_run = part == 0 ? 0u : need;
+                Cand mine; mine.bits = 0; mine.key = kEmpty; mine.pad = 0;
+                if ((u32)tid < n_run) mine = t.sel[tid];                              // (K <= 128 <= BLOCK)
+                GP_SYNC();
+                for (u32 i = tid; i < t.CA; i += BLOCK) { t.akeys[i] = kEmpty; t.avals[i] = 0.0; }
+                if (tid < 64) ctl->bcnt[tid] = 0;
+                if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
+                GP_SYNC();
+                if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
+                {
+                    int l = 0;
+                    log_groups<BLOCK>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const u32 ws = g0 + 64u * (u32)q;
+                            if (ws >= n_log) break;                                   // wave-uniform
+                            const double c = sk_window_coef(ctl, n_levels, ws, (u32)lane, l);
+                            bool hit = k[q] >= 0 && c != 0.0;
+                            if (hit) hit = t.R[((u32)k[q] * kSkMulA) >> t.shR] >= t_c;
+                            insert_window_asm(t.akeys, t.avals, t.CA, &ctl->ovf, hit ? k[q] : -1, c * s[q], P, part);   // graph.h:90 / :109
+                        }
+                    });
+                }
+                GP_SYNC();
+                SKT(ctl, 8);
+                if (uni(ctl->ovf)) { ovf = true; break; }
+                need = sk_select<BLOCK>(p, ctl, t);
+                SKT(ctl, 9);
+                if (need == 0xFFFFFFFFu) { if (tid == 0) ctl->fail = 1; GP_SYNC(); return; }
+            }
+            if (!ovf) break;
+            GP_SYNC();
+            if (tid == 0) ctl->ovf = 0;
+            P *= 2; need = 0;
+            if (P > 64u) { if (tid == 0) ctl->fail = 1; GP_SYNC(); return; }          // (tens of thousands of near-ties: general kernel)
+            GP_SYNC();
+        }
+        // Complete?  An unswept node sits in a cell below t_c, so its total * scale < t_c.  With K exact totals selected and
+        // the K-th of them at tau: tau * scale * (1 - 2^-20) >= t_c puts every unswept node strictly below tau.
+        if (t_c <= 1u || last) break;
+        if (need == K) {
+            const double tau_fx = __builtin_floor(__longlong_as_double((long long)uni(ctl->kth_bits)) * p.sk_rscale * (1.0 - 1.0 / 1048576.0));
+            if (tau_fx >= (double)t_c) break;
+            t_c = tau_fx >= 1.0 ? (u32)tau_fx : 1u;                                    // tau is a proven lower bound on the K-th total
+            last = true;
+        } else {
+            t_c = round >= 2 ? 1u : max(1u, t_c >> 4);                                // fewer than K nodes up there: look lower
+        }
+        if (tid == 0) zstat(ctl, zSweep2, 1);
+    }
+    // order the selected entries (value desc, column asc) and write the row
+    const long long out0 = row * (long long)p.K;
+    for (u32 i = tid; i < need; i += BLOCK) {
+        const Cand cd = t.sel[i];
+        const int ck = (int)((u32)cd.key & p.node_mask);
+        u32 rank = 0;
+        for (u32 j = 0; j < need; ++j) {
+            const Cand o = t.sel[j];
+            const int ok = (int)((u32)o.key & p.node_mask);
+            rank += (o.bits > cd.bits || (o.bits == cd.bits && ok < ck)) ? 1u : 0u;
+        }
+        p.out_row[out0 + rank] = seed;                                                // graph.h:122
+        p.out_col[out0 + rank] = ck;                                                  // graph.h:123
+        p.out_val[out0 + rank] = __longlong_as_double((long long)cd.bits);            // graph.h:124
+    }
+    if (tid == 0) {
+        if (p.out_filled) p.out_filled[row] = (int)need;
+        zstat(ctl, zFilled, need);
+    }
+}
+
+// ---------------------------------------------------------------- the row loop
+template <int BLOCK>
+__device__ __forceinline__ void sk_wipe(const SkView& w) {
+    typedef u32 u4 __attribute__((ext_vector_type(4)));
+    const u4 z = {0u, 0u, 0u, 0u};
+    for (u32 i = 4u * threadIdx.x; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
+    for (u32 i = threadIdx.x; i < w.CX; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
+}
+template <int BLOCK>
+__device__ __forceinline__ void sk_wipe_x(const SkView& w) {
+    for (u32 i = threadIdx.x; i < w.CX; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void gfpush_sk_rows()
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KP p = kparams();
+    const u32 lds0 = uni(lds_addr(smem));
+    const SkView w = sk_view(p, lds0);
+    CtlS* ctl = w.ctl;
+    const int tid = threadIdx.x;
+    const u32 CX = w.CX;
+    sk_wipe<BLOCK>(w);
+    if (tid < 8) { ctl->st[tid] = 0; ctl->st_row[tid] = 0; }
+#ifdef GP_SK_TIMING
+    if (tid < 16) ctl->tacc[tid] = 0;
+    if (tid < 14) ctl->tacc2[tid] = 0;
+#endif
+    if (tid < kSkMaxCoef) { ctl->cand_q[tid] = 0; if (tid < p.n_coef) ctl->coef[tid] = p.coef[tid]; }
+    const long long n_rows = p.n_seeds;
+    u32 max_e = 0, max_log = 0;
+    const int L = p.n_coef - 1;
+    // a level goes straight into the exact table while its edges fit it at <= half load
+    const u32 direct_max = CX / 2u;
+
+    for (;;) {
+        GP_SYNC();
+        SKT_BEGIN(ctl);
+        if (tid == 0) {
+            ctl->row = (long long)__hip_atomic_fetch_add(&p.counters[p.queue_counter], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl->fail = 0; ctl->ovf = 0;
+        }
+        GP_SYNC();
+        const long long row = uni(ctl->row);
+        if (row >= n_rows) break;
+        const int seed = uni(p.seeds[row]);
+        if (seed < 0 || seed >= p.n_nodes) {            // the device API does not pre-validate seeds
+            if (tid == 0) { __hip_atomic_fetch_add(&ctl->st[zFailed], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p.out_filled) p.out_filled[row] = 0; }
+            continue;
+        }
+        const u32 s_start = uni((u32)p.indptr[seed]);
+        const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - s_start;
+        const int seed_key = (int)((u32)seed | (min(seed_deg, p.deg_sat) << p.deg_shift));
+
+        u32 n_ent_cur = 0, e_cur = 0, log_pos = 1;
+        double dang_cur = 0.0; bool has_dang_cur = false;
+        int cur = 1, n_levels = 1;
+        // ---- level 0: the frontier is { seed : 1.0 } (graph.h:81): its record, push test and push-list entry directly
+        {
+            PushEntry* push1 = w.push2 + (size_t)1 * p.push_cap;
+            u32* bt1 = w.bt2 + (size_t)1 * p.bt_cap;
+            if (tid == 0) {
+                if (p.log_cap > 0) { w.log_key[0] = seed_key; w.log_val[0] = 1.0; } else ctl->fail = 1;   // graph.h:90
+                ctl->seg_off[0] = 0;
+                zstat(ctl, zDeg, 1); zstat(ctl, zLevels, 1);
+            }
+            if (L > 0) {
+                if (seed_deg == 0) { dang_cur = 1.0; has_dang_cur = true; }           // graph.h:91-93
+                else if (1.0 >= p.rmax * (double)seed_deg) {                          // graph.h:94
+                    const double share = 1.0 / (double)seed_deg;                      // graph.h:95
+                    if (tid == 0) { zstat(ctl, zPush, 1); zstat(ctl, zEdges, seed_deg); }
+                    if (share != 0.0) {
+                        e_cur = seed_deg; n_ent_cur = 1;
+                        if (tid == 0) {
+                            if (p.push_cap > 0) { PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push1[0] = pe; } else ctl->fail = 1;
+                        }
+                        const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
+                        if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
+                        else for (u32 m = (u32)tid; m < units; m += BLOCK) bt1[m] = 0u;
+                    }
+                }
+            }
+            GP_SYNC();
+            SKT(ctl, 0); SKT_COUNT(ctl, 15, 1);
+        }
+        for (int lvl = 1; lvl <= L; ++lvl) {
+            const u32 n_rec = e_cur + (has_dang_cur ? 1u : 0u);                       // log records (= pushed edges) of this level
+            if (n_rec == 0 || uni(ctl->fail)) break;                                  // the frontier died: later levels add nothing
+            const bool last = lvl == L;                                               // graph.h:104-110: no push from the last level
+            max_e = max(max_e, e_cur);
+            if ((u64)log_pos + n_rec > p.log_cap) { if (tid == 0) ctl->fail = 1; GP_SYNC(); break; }
+            const u32 seg_base = log_pos;
+            LevelCtr* nx = &ctl->lc[lvl & 1];
+            if (tid == 0) {
+                nx->dangling = 0.0; nx->n_dangling = 0; nx->n_rec = 0; nx->alloc = 0ull;
+                ctl->seg_off[lvl] = seg_base;
+                zstat(ctl, zLevels, 1);
+            }
+            n_levels = lvl + 1;
+            log_pos += n_rec;
+            SKT(ctl, 6);
+            if (last) {
+                phase_sk_stream<BLOCK, 2>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, 0u, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+                SKT(ctl, 3);
+                break;
+            }
+            const bool direct = n_rec <= direct_max;
+            u32 capx = direct ? min(CX, max(kMinCap, (4u * n_rec + 3u) & ~3u)) : CX;
+            // Partitions planned for <= 0.6 load of the exact table, from the nodes per pushed edge this workgroup's earlier rows
+            // tabled at this level (a long probing chain costs every lane of its wave; an overflowed pass costs a whole pass)
+            u32 P0 = 1;
+            if (!direct) {
+                const u32 q = uni(ctl->cand_q[lvl]);
+                const u32 est = (u32)(((u64)n_rec * q) >> 10);
+                if (q != 0 && 5u * est > 3u * CX) P0 = min(64u, (5u * est + 3u * CX - 1u) / (3u * CX));
+            }
+            SKT2_BEGIN(ctl);
+            if (direct) phase_sk_stream<BLOCK, 1>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+            else        phase_sk_stream<BLOCK, 0>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+            SKT2(ctl, 11);
+            GP_SYNC();
+            SKT2(ctl, 12);
+            SKT(ctl, direct ? 1 : 2); SKT_COUNT(ctl, direct ? 13 : 14, 1);
+            // Exact inserts, then SCAN.  A table that overflows is wiped and the level's candidates are walked in hash
+            // partitions (q of P, split in two in place), exactly as the general kernel refines its partitions.
+            bool u_dirty = !direct, first = true;
+            u32 part = 0, np = P0;
+            for (;;) {
+                if (!(first && direct)) {
+                    SKT2_BEGIN(ctl);
+                    phase_sk_filter<BLOCK>(lds0, seg_base, n_rec, capx, direct ? 0u : 1u, np, part);
+                    SKT2(ctl, 2);
+                    GP_SYNC();
+                    SKT2(ctl, 3);
+                    SKT(ctl, 4); SKT_COUNT(ctl, 11, 1);
+                }
+                first = false;
+                if (uni(ctl->ovf)) {
+                    sk_wipe_x<BLOCK>(w);
+                    GP_SYNC();
+                    if (tid == 0) ctl->ovf = 0;
+                    capx = CX;
+                    if (np < 0x10000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
+                    if (tid == 0) ctl->fail = 1;
+                    GP_SYNC();
+                    break;
+                }
+                const bool final_part = np == P0 && part + 1u == P0;                  // nothing reads the sketch after this partition
+                SKT2_BEGIN(ctl);
+                phase_sk_scan<BLOCK>(lds0, capx, (u32)(lvl & 1), (u32)(cur ^ 1), final_part && u_dirty ? 1u : 0u);
+                if (final_part) u_dirty = false;
+                SKT2(ctl, 9);
+                GP_SYNC();
+                SKT2(ctl, 10);
+                SKT(ctl, 5); SKT_COUNT(ctl, 12, 1);
+                if (uni(ctl->fail)) break;
+                while (np > P0 && (part & 1u)) { part >>= 1; np >>= 1; }
+                ++part;
+                if (np == P0 && part == P0) break;
+            }
+            if (u_dirty) {                                                            // (a split partition walk of a sketch level)
+                typedef u32 u4 __attribute__((ext_vector_type(4)));
+                const u4 z = {0u, 0u, 0u, 0u};
+                for (u32 i = 4u * (u32)tid; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
+                GP_SYNC();
+            }
+            if (uni(ctl->fail)) break;
+            if (tid == 0 && !direct) {                                                // nodes the exact table held per pushed edge, x 1.25, decaying maximum
+                const u32 obs = min(2048u, (u32)(1280.0f * (float)nx->n_rec * __frcp_rn((float)n_rec)) + 8u);
+                const u32 old_q = ctl->cand_q[lvl];
+                ctl->cand_q[lvl] = max(obs, old_q - (old_q >> 3));
+            }
+            { const u64 al = uni(nx->alloc); n_ent_cur = (u32)al; e_cur = (u32)(al >> 32); }
+            has_dang_cur = uni(nx->n_dangling) != 0; dang_cur = has_dang_cur ? uni(nx->dangling) : 0.0;
+            cur ^= 1;
+        }
+        if (tid == 0) ctl->seg_off[n_levels] = log_pos;
+        GP_SYNC();
+        SKT(ctl, 6);
+        max_log = max(max_log, log_pos);
+        if (!uni(ctl->fail))
+            phase_sk_topk<BLOCK>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, n_levels, log_pos);
+        GP_SYNC();
+        if (uni(ctl->fail)) {
+            // the row leaves for the retry list (the general kernel recounts it); nothing of it was written
+            if (tid == 0) {
+                const u64 i = __hip_atomic_fetch_add(&p.counters[p.retry_counter], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.retry_list[i] = (u32)row;
+            }
+            if (tid < 8) ctl->st_row[tid] = 0;
+        } else if (tid < 8) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }
+        GP_SYNC();
+        sk_wipe<BLOCK>(w);                                                            // TOP-K used the level tables' bytes
+        SKT(ctl, 10);
+    }
+    GP_SYNC();
+    if (tid == 0) {
+        const Counter dst[zNumStats] = { kPushes, kEdges, kDegLookups, kFilled, kLdsLevels, kFailedRows, kSkCandEdges, kSkSweep2 };
+#pragma unroll
+        for (int i = 0; i < zNumStats; ++i)
+            if (ctl->st[i]) __hip_atomic_fetch_add(&p.counters[dst[i]], ctl->st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (max_e) __hip_atomic_fetch_max(&p.counters[kMaxLevelEdges], (u64)max_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (max_log) __hip_atomic_fetch_max(&p.counters[kMaxLogRecords], (u64)max_log, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GP_SK_TIMING
+        for (int i = 0; i < 16; ++i) __hip_atomic_fetch_add(&p.counters[kDiag0 + i], ctl->tacc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 14; ++i) __hip_atomic_fetch_add(&p.counters[kDiagX0 + i], ctl->tacc2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 6) gfpush_sk_kernel(const KParams)
+{
+    gfpush_sk_rows<BLOCK>();
+}
+
+}  // namespace gp
+
+#endif  // !GP_DIAG

@@ -201,30 +201,6 @@ bool hip_ok(hipError_t e, const char* what) {
 
 }  // namespace
 
-// Measurement aid (bench.py): the shader clock the GPU is running at right now.  One wave spins for ~200 us of the constant
-// 100 MHz wall clock and reports how many shader cycles (s_memtime) went by.
-__global__ void clock_probe_kernel(unsigned long long* out) {
-    const unsigned long long c0 = clock64(), w0 = wall_clock64();
-    unsigned long long w1 = w0;
-    while (w1 - w0 < 20000ull) w1 = wall_clock64();
-    const unsigned long long c1 = clock64();
-    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
-}
-
-// What the device can do right now, independent of any counter's time base: a dependent chain of integer multiply-adds in
-// one wave (ALU iterations per microsecond of the constant 100 MHz clock: proportional to the shader clock) ...
-__global__ void alu_probe_kernel(unsigned long long* out, int iters) {
-    unsigned int x = threadIdx.x + 1u;
-    const unsigned long long w0 = wall_clock64();
-    for (int i = 0; i < iters; ++i) { x = x * 1664525u + 1013904223u; asm volatile("" : "+v"(x)); }
-    const unsigned long long w1 = wall_clock64();
-    if (threadIdx.x == 0) { out[0] = w1 - w0; out[1] = x; }
-}
-// ... and a streaming copy over the whole chip (GB/s of HBM traffic, read + write).
-__global__ void copy_probe_kernel(const uint4* src, uint4* dst, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
 extern "C" {
 
 int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim, const float* d_edge_weight,
@@ -313,53 +289,6 @@ int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim
     if (mode == 2) { if (!hip_ok(hipMemcpyAsync(d_out, cur, nf * sizeof(float), hipMemcpyDeviceToDevice, s), "hipMemcpyAsync")) return GP_ERR_HIP; }
     if (!hip_ok(hipGetLastError(), "propagate kernels")) return GP_ERR_HIP;
     return GP_OK;                                          // ~Scratch frees
-}
-
-int gp_internal_clock_mhz(int device, double* shader_mhz) {
-    if (!shader_mhz) return GP_ERR_NULL;
-    *shader_mhz = 0.0;
-    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return GP_ERR_HIP;
-    unsigned long long* d = nullptr; unsigned long long h[2] = {0, 0};
-    if (!hip_ok(hipMalloc(&d, sizeof h), "hipMalloc")) return GP_ERR_HIP;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, 0, d);
-    const bool ok = hip_ok(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost), "hipMemcpy");
-    (void)hipFree(d);
-    if (!ok) return GP_ERR_HIP;
-    if (h[1]) *shader_mhz = 100.0 * (double)h[0] / (double)h[1];
-    return GP_OK;
-}
-
-int gp_internal_speed_probe(int device, double* alu_iters_per_us, double* copy_gb_s) {
-    if (!alu_iters_per_us || !copy_gb_s) return GP_ERR_NULL;
-    *alu_iters_per_us = 0.0; *copy_gb_s = 0.0;
-    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return GP_ERR_HIP;
-    const long long n16 = (long long)(256u << 20) / 16;                       // 256 MiB each way
-    unsigned long long* d = nullptr; uint4* a = nullptr; uint4* b = nullptr; unsigned long long h[2] = {0, 0};
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ok = hip_ok(hipMalloc(&d, sizeof h), "hipMalloc") && hip_ok(hipMalloc(&a, (size_t)n16 * 16), "hipMalloc") &&
-              hip_ok(hipMalloc(&b, (size_t)n16 * 16), "hipMalloc") && hip_ok(hipEventCreate(&e0), "hipEventCreate") &&
-              hip_ok(hipEventCreate(&e1), "hipEventCreate");
-    if (ok) {
-        const int iters = 1 << 16;
-        hipLaunchKernelGGL(alu_probe_kernel, dim3(1), dim3(64), 0, 0, d, iters);
-        ok = hip_ok(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost), "hipMemcpy");
-        if (ok && h[0]) *alu_iters_per_us = 100.0 * (double)iters / (double)h[0];
-    }
-    if (ok) {
-        hipLaunchKernelGGL(copy_probe_kernel, dim3(4096), dim3(256), 0, 0, a, b, n16);       // first touch
-        (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(copy_probe_kernel, dim3(4096), dim3(256), 0, 0, a, b, n16);
-        (void)hipEventRecord(e1, 0);
-        float ms = 0.f;
-        ok = hip_ok(hipEventSynchronize(e1), "hipEventSynchronize") && hip_ok(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
-        if (ok && ms > 0.f) *copy_gb_s = 2.0 * (double)n16 * 16.0 / ((double)ms * 1e6);
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (d) (void)hipFree(d);
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    return ok ? GP_OK : GP_ERR_HIP;
 }
 
 }  // extern "C"

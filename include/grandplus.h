@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GP_ABI_VERSION 2
+#define GP_ABI_VERSION 3
 
 /* Status codes (0 = success).  The Python / pybind11 shims map INVALID_* to
  * ValueError, NO_DEVICE / HIP / OVERFLOW to RuntimeError, NOMEM to MemoryError. */
@@ -70,6 +70,14 @@ typedef struct gp_stats {
     int64_t retried_rows;    /* rows that took that second launch (they are complete and exact, just slower) */
     int64_t max_level_edges; /* largest number of edges one level of one row traversed                       */
     int64_t max_log_records; /* largest number of reserve-log records (sum over levels of frontier size) of one row */
+    /* ABI 3: which kernel ran the rows.  2 = the sketch-filtered kernel (csrc/gfpush_sketch.hpp: keyless fixed-point upper
+     * bounds decide which targets get an exact fp64 accumulator; `frontier` and `support` are not counted by it and stay 0,
+     * its log holds one record per pushed edge, so max_log_records counts edges), 1 = the general kernel
+     * (csrc/gfpush_kernels.hpp), which also re-runs the rows the sketch kernel hands back (retried_rows). */
+    int32_t kernel;
+    int32_t sketch_pad;
+    int64_t sketch_candidate_edges;  /* pushed edges whose target might push and went into the exact table (of `edges`) */
+    int64_t sketch_second_sweeps;    /* rows whose top-K needed a second sweep over their log                          */
 } gp_stats;
 
 /* ABI / build information. */
@@ -170,6 +178,12 @@ int gp_reset_stats(gp_graph* g);
  *                      whose CSR rows hold strictly increasing column ids the seed's neighbour list IS level 1's frontier)
  *   "solo_levels"     0 = levels of <= 256 edges go through EXPAND + SCAN of the whole workgroup (default 1: one wave does such a
  *                      level start to finish, the others park at one barrier)
+ *   "kernel"          0 = choose per call (default), 1 = always the general kernel, 2 = the sketch-filtered kernel whenever
+ *                      the call allows it (all coef >= 0, at most 40 levels, K <= 128, rmax > 0).  Automatic choice: the
+ *                      sketch kernel for rmax >= 5e-6 on graphs whose node count exceeds the direct-indexed table
+ *   "sk_block_threads" / "sk_lg_mu" / "sk_lg_mr" / "sk_target"   geometry of the sketch kernel (0 = default): threads per
+ *                      workgroup (512 = three per CU with 52 KB, 768 = two with 80 KB), log2 cells of the level sketch and
+ *                      of the reserve sketch, cell rank of the first TOP-K threshold (default 2 K)
  *   "diag_flags"      ignored by the product library; the diagnostic build (-DGP_DIAG) skips phases for
  *                      instruction attribution (bit 0: TOP-K) -- its results are then meaningless
  * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.
@@ -238,13 +252,6 @@ int gp_internal_multi_plan(int64_t n_seeds, int K, int n_parts, int64_t min_rows
 
 /* internal: lets the second translation unit report through gp_last_error (not for callers) */
 void gp_internal_set_error(int status, const char* where, const char* detail);
-/* Measurement aid (bench.py, not part of the reference's interface): the shader clock `device` runs at right now, in MHz --
- * shader cycles counted by one wave over ~200 us of the constant 100 MHz clock. */
-int gp_internal_clock_mhz(int device, double* shader_mhz);
-/* Measurement aid: what `device` delivers right now, independent of any counter's time base -- iterations per microsecond of a
- * dependent integer multiply-add chain in one wave (proportional to the shader clock) and GB/s (read + write) of a 256 MiB
- * streaming copy over the whole chip. */
-int gp_internal_speed_probe(int device, double* alu_iters_per_us, double* copy_gb_s);
 
 #ifdef __cplusplus
 }

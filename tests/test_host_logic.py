@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"libgrandplus.so does not export {name}"
-    assert _native.lib().gp_abi_version() == 2
+    assert _native.lib().gp_abi_version() == 3
     assert _native.lib().gp_strerror(2) == b"invalid CSR"
 
 

@@ -4,7 +4,7 @@ times the same batches again: tells an allocation-placement effect from a time-b
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-import bench
+import bench, device_probe
 from grand_plus_amd import Graph, _native
 from grand_plus_amd.recipes import RECIPES
 
@@ -29,5 +29,5 @@ def run(g, tag):
 for attempt in range(4):
     g = Graph(ip, ix, 0)
     slow = run(g, "graph%d" % attempt)
-    print("graph%d" % attempt, "slow" if slow else "fast", "probe", _native.speed_probe(0), flush=True)
+    print("graph%d" % attempt, "slow" if slow else "fast", "probe", device_probe.speed_probe(0), flush=True)
     g.close()

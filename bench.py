@@ -212,11 +212,37 @@ def parse_args():
     return ap.parse_args()
 
 
+# Test seam (tests/test_bench_gloo.py): with GRANDPLUS_BENCH_DEVICE=cpu the rank code runs its orchestration -- sharding, warm-up,
+# fences, the gather, the max-over-ranks reductions, the JSON line -- on CPU tensors with the Graph class the TEST injects here.
+# There is no CPU implementation of the path behind it: without an injected class the run stops with an error.
+_GRAPH_FACTORY = None
+
+
+class _HostEvent:
+    """torch.cuda.Event stand-in of the CPU test seam (perf_counter stamps)."""
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
 def run_rank(args) -> int:
     import torch
     import torch.distributed as dist
     from grand_plus_amd import Graph, RECIPES, algorithmic_bytes
     from grand_plus_amd.sharded import PackedRows, gfpush_sharded
+    cpu_seam = os.environ.get("GRANDPLUS_BENCH_DEVICE") == "cpu"
+    if cpu_seam:
+        if _GRAPH_FACTORY is None:
+            print("[bench] GRANDPLUS_BENCH_DEVICE=cpu is a test seam: there is no CPU path to benchmark", file=sys.stderr)
+            return 3
+        Graph = _GRAPH_FACTORY
+    Event = _HostEvent if cpu_seam else torch.cuda.Event
+    dev_sync = (lambda d: None) if cpu_seam else torch.cuda.synchronize
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -266,8 +292,9 @@ def run_rank(args) -> int:
             dist.destroy_process_group()
         return 3
     t_upload = time.perf_counter() - t0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not cpu_seam:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if cpu_seam else torch.device("cuda", local_rank)
     if args.block_threads:
         graph.set_option("block_threads", args.block_threads)
     if args.lds_bytes:
@@ -313,10 +340,10 @@ def run_rank(args) -> int:
             gathered.copy_(host)
 
     def fence():
-        torch.cuda.synchronize(dev)
+        dev_sync(dev)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            dev_sync(dev)
 
     # Untimed launches in front of the W warmup steps the driver asks for: a freshly started process spends its first launches on
     # first-touch page faults of the workspace, code-object upload and clock ramp-up (the first MAG launch takes 38-41 ms against
@@ -326,14 +353,14 @@ def run_rank(args) -> int:
     prewarm = 0 if args.no_settle else max(0, args.prewarm)
     pre_ms = []
     for _ in range(prewarm):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); step(0); b.record(); torch.cuda.synchronize(dev)
+        a, b = Event(enable_timing=True), Event(enable_timing=True)
+        a.record(); step(0); b.record(); dev_sync(dev)
         pre_ms.append(a.elapsed_time(b))
     for i in range(args.warmup):
         step(i)
     fence()
     graph.reset_stats()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(Event(enable_timing=True), Event(enable_timing=True)) for _ in range(args.steps)]
     t_start = time.perf_counter()
     for j in range(args.steps):
         i = args.warmup + j

@@ -700,11 +700,11 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         sk_block = g->sk_block ? g->sk_block : 768;
         sk_lds = sk_block == 512 ? kThreeLds : 80 * 1024;
         sk_lg_mu = (u32)(g->sk_lg_mu ? g->sk_lg_mu : (sk_block == 512 ? 12 : 13));
-        sk_lg_mr = (u32)(g->sk_lg_mr ? g->sk_lg_mr : (sk_block == 512 ? 12 : 13));
-        const int64_t x_bytes = (int64_t)sk_lds - kCtlBytes - (4ll << sk_lg_mu);
+        sk_lg_mr = (u32)(g->sk_lg_mr ? g->sk_lg_mr : 11);
+        const int64_t x_bytes = (int64_t)sk_lds - kCtlBytes - (4ll << sk_lg_mu) - (4ll << sk_lg_mr);
         sk_cx = x_bytes > 0 ? (u32)(x_bytes / 12) & ~3u : 0u;
-        // the exact table, and the aggregation table TOP-K builds behind its reserve sketch in the same bytes, need >= kMinCap slots
-        const int64_t ca = ((4ll << sk_lg_mu) + 12ll * sk_cx - (4ll << sk_lg_mr) - 16ll * ((int64_t)kSkTie + K)) / 12;
+        // the exact table, and the aggregation table TOP-K builds over the level sketch + exact table, need >= kMinCap slots
+        const int64_t ca = ((4ll << sk_lg_mu) + 12ll * sk_cx - 16ll * ((int64_t)kSkTie + K)) / 12;
         if (sk_cx < kMinCap || ca < (int64_t)kMinCap) {
             if (g->kernel == 2 && (g->sk_lg_mu || g->sk_lg_mr)) return fail(GP_ERR_INVALID_ARG, "sketch sizes leave no room for the exact table (sk_lg_mu %u, sk_lg_mr %u)", sk_lg_mu, sk_lg_mr);
             use_sk = false;
@@ -851,7 +851,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         kp.row_map = nullptr; kp.n_rows_dev = nullptr; kp.queue_counter = kQueue;
         kp.retry_list = w.retry_list; kp.retry_counter = kRetryRows;
         kp.sk_lg_mu = sk_lg_mu; kp.sk_lg_mr = sk_lg_mr; kp.sk_cx = sk_cx;
-        kp.sk_target = (u32)(g->sk_target > 0 ? g->sk_target : 2 * K);
+        kp.sk_target = (u32)(g->sk_target > 0 ? g->sk_target : 4 * K);
         kp.sk_rscale = 2147483648.0 / std::max(1.0, coef_sum);
         {   // rmax * 2^31 * (1 - 2^-10), rounded DOWN to fp32: cell >= packed degree * this is necessary for r >= rmax * deg
             float t = (float)(rmax * 2147483648.0 * (1.0 - 1.0 / 1024.0));

@@ -18,7 +18,8 @@
 // Per level l = 1..L of a row (graph.h:83-110):
 //   STREAM  edge_stream over the push list (one lane per edge, gfpush_kernels.hpp): the packed column word and the
 //           pusher's share go to the reserve LOG at position (level base + edge number) -- no allocation, fully
-//           coalesced -- and ceil(share * 2^31) into the level sketch U.  Small levels skip U and insert straight into
+//           coalesced --, ceil(share * 2^31) into the level sketch U and ceil(coef[l] * share * scale) into the row's
+//           RESERVE SKETCH R (see TOP-K), both fire-and-forget LDS adds.  Small levels skip U and insert straight into
 //           the exact table.
 //   FILTER  re-reads the level's log segment (L2-hot, next group of 256 records in flight while one is processed), looks
 //           every edge's cell up and inserts the edges whose target may push into the exact table X (insert_window_asm:
@@ -27,9 +28,10 @@
 //   SCAN    drains X: exact push test with the packed degree, indptr lookup for the nodes that pass, dangling rule
 //           (graph.h:91-93), fp64 division, next push list (push_alloc).  A tenth of the round-3 SCAN's items and no log
 //           append: the records were written per edge by STREAM.
-// TOP-K (graph.h:111-126), with the level tables dead and all of the LDS free:
-//   R[h(v)] += ceil(coef[level] * share * scale) over the whole log (one pipelined sweep) is an upper bound on every
-//   node's reserve, so the K largest totals live in heavy cells.  The cell value t_c of rank ~2K is read off a histogram
+// TOP-K (graph.h:111-126), with the level tables dead and their LDS free:
+//   R[h(v)] += ceil(coef[level] * share * scale) over every pushed edge is an upper bound on every node's reserve, so the
+//   K largest totals live in heavy cells.  (Building R by one more sweep over the log at TOP-K time instead -- 16 KB more
+//   exact table during the levels -- measured 20 us per MAG row against ~1 us for the adds in STREAM.)  The cell value t_c of rank ~2K is read off a histogram
 //   of R, a second sweep sums (exactly, fp64, keyed table) the records whose cell reaches t_c, and if the K-th largest
 //   exact total tau satisfies tau*scale >= t_c no unswept node can beat it: done (95 % of MAG rows; ~200 nodes tabled
 //   instead of the 12 500 of the support).  Otherwise tau is a proven lower bound and one more sweep with t_c = tau*scale
@@ -93,20 +95,20 @@ __device__ __forceinline__ void zstat(CtlS* ctl, int which, u64 n) {
     __hip_atomic_fetch_add(&ctl->st_row[which], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// LDS of a workgroup: CtlS + the per-wave flag bytes (kCtlBytes, as in the general kernel) | U u32[MU] | X values f64[CX] |
-// X keys i32[CX].  TOP-K re-uses all of it behind the control block as
-// { R u32[MR] | aggregation values f64[CA] | keys i32[CA] | tie Cand[256] | sel Cand[K] }.
+// LDS of a workgroup: CtlS + the per-wave flag bytes (kCtlBytes, as in the general kernel) | R u32[MR] | U u32[MU] |
+// X values f64[CX] | X keys i32[CX].  TOP-K re-uses U and X as { aggregation values f64[CA] | keys i32[CA] | tie Cand[256] | sel Cand[K] }.
 struct SkView {
-    CtlS* ctl; u32* U; double* xvals; int* xkeys; u32 MU, CX, shU;
+    CtlS* ctl; u32* R; u32* U; double* xvals; int* xkeys; u32 MU, MR, CX, shU, shR;
     PushEntry* push2; u32* bt2; int* log_key; double* log_val;
     u32 lds_u;                            // byte offset of U inside LDS
 };
 __device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
     SkView w;
-    w.MU = 1u << p.sk_lg_mu; w.CX = p.sk_cx;
-    w.shU = 32u - p.sk_lg_mu;
+    w.MU = 1u << p.sk_lg_mu; w.MR = 1u << p.sk_lg_mr; w.CX = p.sk_cx;
+    w.shU = 32u - p.sk_lg_mu; w.shR = 32u - p.sk_lg_mr;
     w.ctl = lds_at<CtlS>(lds0);
-    w.lds_u = lds0 + (u32)kCtlBytes;
+    w.R = lds_at<u32>(lds0 + (u32)kCtlBytes);
+    w.lds_u = lds0 + (u32)kCtlBytes + 4u * w.MR;
     w.U = lds_at<u32>(w.lds_u);
     w.xvals = lds_at<double>(w.lds_u + 4u * w.MU);
     w.xkeys = lds_at<int>(w.lds_u + 4u * w.MU + 8u * w.CX);
@@ -124,7 +126,7 @@ __device__ __forceinline__ void lds_add_u32(u32* cell, u32 v) {
 __device__ __forceinline__ u32 fx_up(double x) { return (u32)__builtin_ceil(x); }
 
 // Walks log records [0, n) in groups of 256 (four 64-lane windows), groups dealt to the waves round robin; f(key[4], val[4],
-// first record of the group) runs while the NEXT group's eight loads are in flight.  Lanes past n get key -1.
+// first record of the group) runs while the NEXT group's eight loads are in flight.  Lanes past n get key -1 (n >= 1).
 template <int BLOCK, class F>
 __device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 n, F f)
 {
@@ -132,20 +134,21 @@ __device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 
     const u32 lane = threadIdx.x & 63u;
     u32 g = wave_id() * 256u;
     if (g >= n) return;
+    // (every load is unconditional -- a lane past n re-reads the last record and is masked when the group is consumed: a
+    //  conditional load merges control flow between issue and use, and the compiler then waits for ALL loads in flight)
     int kn[4]; double sn[4];
     auto load = [&](u32 g0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const u32 i = g0 + 64u * (u32)q + lane;
-            kn[q] = -1; sn[q] = 0.0;
-            if (i < n) { kn[q] = lk[i]; sn[q] = lv[i]; }
+            const u32 i = min(g0 + 64u * (u32)q + lane, n - 1u);
+            kn[q] = lk[i]; sn[q] = lv[i];
         }
     };
     load(g);
     for (;;) {
         int k[4]; double s[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { k[q] = kn[q]; s[q] = sn[q]; }
+        for (int q = 0; q < 4; ++q) { const bool in = g + 64u * (u32)q + lane < n; k[q] = in ? kn[q] : -1; s[q] = in ? sn[q] : 0.0; }
         const u32 cur = g;
         g += kStride;
         const bool more = g < n;                                      // wave-uniform
@@ -156,13 +159,14 @@ __device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 
 }
 
 // ---------------------------------------------------------------- STREAM
-// MODE 0: log + level sketch U.   MODE 1: log + exact insert into X (small levels).   MODE 2: log only (last level).
+// MODE 0: log + reserve sketch + level sketch U.   MODE 1: log + reserve sketch + exact insert into X (small levels).
+// MODE 2: log + reserve sketch (last level).   cs = coef[level] * scale: reserve-sketch units per unit of share.
 template <int BLOCK, int MODE>
-__device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, u32 capx,
+__device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, double cs, u32 capx,
                                                   u32 has_dang, double dang, int seed_key)
 {
     KP p = kparams();
-    lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); capx = uni(capx);
+    lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs); capx = uni(capx);
     has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key);
     const SkView w = sk_view(p, lds0);
     const u32 lane = threadIdx.x & 63u;
@@ -174,14 +178,18 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
             if (v[q] >= 0) {
                 const u32 li = t0 + 64u * (u32)q + lane;                              // the edge's number inside the level
                 lk[li] = v[q]; lv[li] = sh[q];                                        // graph.h:98 -> one log record per edge
-                if (MODE == 0) lds_add_u32(&w.U[((u32)v[q] * kSkMulA) >> w.shU], fx_up(sh[q] * 2147483648.0));
+                const u32 h = (u32)v[q] * kSkMulA;
+                if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(sh[q] * cs));       // graph.h:90 / :109, as an upper bound
+                if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(sh[q] * 2147483648.0));
             }
             if (MODE == 1) insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q], 1u, 0u);
         }
     });
     if (threadIdx.x == 0 && has_dang) {                                               // graph.h:92: the seed gets the dangling mass
         lk[E] = seed_key; lv[E] = dang;
-        if (MODE == 0) lds_add_u32(&w.U[((u32)seed_key * kSkMulA) >> w.shU], fx_up(dang * 2147483648.0));
+        const u32 h = (u32)seed_key * kSkMulA;
+        if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(dang * cs));
+        if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(dang * 2147483648.0));
         if (MODE == 1 && !res_add_lds(w.xkeys, w.xvals, capx, seed_key, dang)) w.ctl->ovf = 1;
     }
 }
@@ -200,14 +208,16 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
     u32 n_cand = 0;
     SKT2(w.ctl, 0);
     log_groups<BLOCK>(w.log_key + seg_base, w.log_val + seg_base, n, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
+        u32 cell[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cell[q] = w.U[((u32)max(k[q], 0) * kSkMulA) >> w.shU];    // four lookups in flight
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (g0 + 64u * (u32)q >= n) break;                                        // wave-uniform
             bool cand = k[q] >= 0;
             if (use_u && cand) {
-                const u32 cell = w.U[((u32)k[q] * kSkMulA) >> w.shU];
                 const u32 dq = (u32)k[q] >> p.deg_shift;                              // min(deg, deg_sat); 0: dangling, always exact
-                cand = (float)cell >= (float)dq * thr;                                // thr = rmax * 2^31 * (1 - 2^-10), rounded down
+                cand = (float)cell[q] >= (float)dq * thr;                             // thr = rmax * 2^31 * (1 - 2^-10), rounded down
             }
             n_cand += (u32)__popcll(__ballot(cand));
             insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, cand ? k[q] : -1, s[q], parts, part);   // graph.h:98
@@ -339,17 +349,132 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
     SKT2(ctl, 8);
 }
 
+// ---------------------------------------------------------------- small levels by one wave
+// A level of at most 256 edges from at most 64 push-list entries (levels 1, 9, 10 of a MAG row; most levels of a short row),
+// done by ONE wave start to finish: one step of the edge enumeration with the whole push list in the wave's lanes, log
+// records and reserve-sketch adds per edge, exact inserts through insert_window_solo -- which tells a lane whether it CLAIMED
+// its slot, so the claimed slots ARE the level's frontier and SCAN runs straight over that list, no table walk -- with
+// nothing but the wave's program order in between (LDS operations of one wave execute in order).  The other waves skip the
+// call and park at the one barrier behind it (the general path: two calls per wave, two barriers, a table walk).  An insert
+// that hits the probe limit (ctl->ovf) undoes the claims; the caller then walks the level's log like any overflowed level.
+constexpr u32 kSkSoloEdges = 256;
+template <int BLOCK>
+__device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, double cs,
+                                                u32 has_dang, double dang, int seed_key, u32 nx_sel)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs);
+    has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); nx_sel = uni(nx_sel);
+    const SkView w = sk_view(p, lds0);
+    CtlS* ctl = w.ctl; int* lkeys = w.xkeys; double* lvals = w.xvals;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 cap = kMinCap;
+    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct;                 // wave 0's flag bytes
+    u32* list = (u32*)((unsigned char*)ctl + kCtlStruct + 64 * kFlatW);     // the flag areas of the other waves (>= 257 words): they are parked
+    static_assert((BLOCK / 64 - 1) * 64 * kFlatW >= 4 * (kSkSoloEdges + 1), "the claimed-slot list lives in the parked waves' flag bytes");
+    LevelCtr* nx = &ctl->lc[nx_sel];
+    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
+    PushEntry* push_nxt = w.push2 + (size_t)(cur ^ 1u) * p.push_cap;
+    u32* bt_nxt = w.bt2 + (size_t)(cur ^ 1u) * p.bt_cap;
+    int* lk = w.log_key + seg_base; double* lv = w.log_val + seg_base;
+    // ---- the one step of the edge enumeration (as sk/edge_stream: entries flag their first edge, ballot, mbcnt, bpermute)
+    const PushEntry ent = push_cur[min(lane, n_ent - 1u)];
+    const u32 off = lane < n_ent ? ent.off : 0xFFFFFFFFu;
+    *(u32*)(wscr + 4 * lane) = 0u;
+    if (off > 0u && off < E) wscr[(off & 63u) * 4u + (off >> 6)] = 1;
+    asm volatile("" ::: "memory");            // the word is written by OTHER lanes
+    const u32 fl = *(const u32*)(wscr + 4 * lane);
+    u32 before = (u32)__popcll(__ballot(off == 0u)) - 1u;
+    int col[4]; double sh[4];
+    {
+        u32 e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool mine = ((fl >> (8 * q)) & 1u) != 0;
+            const u64 M = __ballot(mine);
+            e[q] = (before + lane_prefix(M) + (mine ? 1u : 0u)) << 2;
+            before += (u32)__popcll(M);
+        }
+        const u64 sbits = (u64)__double_as_longlong(ent.share);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)ent.rel);
+            const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)sbits);
+            const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)(sbits >> 32));
+            const u32 eq = 64u * (u32)q + lane;
+            col[q] = p.indices[eq < E ? rel_e + eq : (u32)p.nnz];           // graph.h:97
+            sh[q] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+        }
+    }
+    u32 n_list = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {             // the four windows, then the mass dangling nodes returned to the seed (graph.h:92)
+        if (q == 4 && !has_dang) break;
+        const int kq = q < 4 ? col[q] : (lane == 0 ? seed_key : -1);
+        const double vq = q < 4 ? sh[q] : dang;
+        if (kq >= 0) {
+            const u32 li = q < 4 ? 64u * (u32)q + lane : E;
+            lk[li] = kq; lv[li] = vq;                                       // graph.h:98 -> one log record per edge
+            if (cs != 0.0) lds_add_u32(&w.R[((u32)kq * kSkMulA) >> w.shR], fx_up(vq * cs));
+        }
+        u32 slot; int seen;
+        insert_window_solo(lkeys, lvals, cap, &ctl->ovf, kq, vq, slot, seen);
+        const bool fresh = kq >= 0 && seen == kEmpty;                       // this lane claimed the slot: a new frontier node
+        const u64 M = __ballot(fresh);
+        if (fresh) list[n_list + lane_prefix(M)] = slot;
+        n_list += (u32)__popcll(M);
+    }
+    asm volatile("" ::: "memory");
+    if (uni(ctl->ovf)) {                      // undo: the claimed slots are all there is
+        for (u32 j = lane; j < n_list; j += 64u) { const u32 sl = list[j]; lkeys[sl] = kEmpty; lvals[sl] = 0.0; }
+        return;
+    }
+    // ---- SCAN over the claimed slots
+    u32 st_push = 0, st_edges = 0, st_deg = 0;
+    for (u32 j = 0; j < n_list; j += 64u) {
+        const bool valid = j + lane < n_list;
+        int k = kEmpty; double r = 0.0;
+        if (valid) {
+            const u32 sl = list[j + lane];
+            k = lkeys[sl]; r = lvals[sl];
+            lkeys[sl] = kEmpty; lvals[sl] = 0.0;
+        }
+        const u32 dq = (u32)k >> p.deg_shift;
+        const bool cand = valid && (dq == 0u || r >= p.rmax * (double)dq);
+        double share = 0.0; u32 len = 0, ds = 0;
+        if (cand) {
+            const int node = (int)((u32)k & p.node_mask);
+            ds = (u32)p.indptr[node]; const u32 deg = (u32)p.indptr[node + 1] - ds; ++st_deg;          // graph.h:43-45
+            if (deg == 0) {                                                                           // graph.h:91-93
+                __hip_atomic_fetch_add(&nx->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (r >= p.rmax * (double)deg) {                                                   // graph.h:94
+                ++st_push; st_edges += deg;
+                const double s_ = r / (double)deg;                                                    // graph.h:95
+                if (s_ != 0.0) { share = s_; len = deg; }
+            }
+        }
+        push_alloc(p, ctl, nx, push_nxt, bt_nxt, len, ds, share, (int)lane);
+    }
+    st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
+    if (lane == 0) {
+        nx->n_rec = n_list;
+        if (st_deg) zstat(ctl, zDeg, st_deg);
+        if (st_push) { zstat(ctl, zPush, st_push); zstat(ctl, zEdges, st_edges); }
+    }
+}
+
 // ---------------------------------------------------------------- TOP-K
 struct SkTop {                             // TOP-K's carving of the LDS behind the control block
     u32* R; u32 MR, shR; double* avals; int* akeys; u32 CA; Cand* tie; Cand* sel; u32* fine;
 };
 __device__ __forceinline__ SkTop sk_top(KP p, const SkView& w) {
     SkTop t;
-    t.MR = 1u << p.sk_lg_mr; t.shR = 32u - p.sk_lg_mr;
-    t.R = lds_at<u32>(w.lds_u);
-    const u32 region_bytes = 4u * w.MU + 12u * w.CX - 4u * t.MR;
+    t.MR = w.MR; t.shR = w.shR;
+    t.R = w.R;
+    const u32 region_bytes = 4u * w.MU + 12u * w.CX;
     t.CA = ((region_bytes - 16u * (kSkTie + (u32)p.K)) / 12u) & ~3u;
-    const u32 a0 = w.lds_u + 4u * t.MR;
+    const u32 a0 = w.lds_u;
     t.avals = lds_at<double>(a0);
     t.akeys = lds_at<int>(a0 + 8u * t.CA);
     t.tie = lds_at<Cand>(a0 + 12u * t.CA);
@@ -357,26 +482,31 @@ __device__ __forceinline__ SkTop sk_top(KP p, const SkView& w) {
     t.fine = (u32*)((unsigned char*)w.ctl + kCtlStruct);                              // 1 024 words of flag bytes, idle in TOP-K
     return t;
 }
-// coef[level] of the records of one 64-lane window starting at record ws; `l` = the wave's level cursor (windows arrive in
-// increasing order).  Windows that straddle a level boundary -- the first levels hold a handful of records -- look it up per lane.
-__device__ __forceinline__ double sk_window_coef(const CtlS* ctl, int n_levels, u32 ws, u32 lane, int& l)
+// coef[level] of the records of one 64-lane window starting at record ws.  The level boundaries live in registers: lane l of
+// the wave holds seg_hi = seg_off[l + 1] (lanes >= n_levels: 0xFFFFFFFF) and cf = coef[l], so the window's level is a ballot
+// and its coefficient a readlane -- no LDS round trip.  Windows that straddle a boundary (the first levels hold a handful of
+// records) step through the levels they touch.
+__device__ __forceinline__ double sk_window_coef(u32 seg_hi, double cf, int n_levels, u32 ws, u32 lane)
 {
-    while (l + 1 < n_levels && ws >= uni(ctl->seg_off[l + 1])) ++l;
-    double c = uni(ctl->coef[l]);
-    if (l + 1 < n_levels && ws + 64u > uni(ctl->seg_off[l + 1])) {
-        int ll = l;
-        const u32 idx = ws + lane;
-        while (ll + 1 < n_levels && idx >= ctl->seg_off[ll + 1]) ++ll;
-        c = ctl->coef[ll];
+    const u32 lo = (u32)(u64)__double_as_longlong(cf), hi = (u32)((u64)__double_as_longlong(cf) >> 32);
+    int l = (int)__popcll(__ballot(seg_hi <= ws));                                    // levels that end at or before ws
+    if (l >= n_levels) l = n_levels - 1;
+    u32 clo = (u32)__builtin_amdgcn_readlane((int)lo, l), chi = (u32)__builtin_amdgcn_readlane((int)hi, l);
+    const u32 idx = ws + lane;
+    while (l + 1 < n_levels && ws + 64u > (u32)__builtin_amdgcn_readlane((int)seg_hi, l)) {   // wave-uniform
+        const u32 edge = (u32)__builtin_amdgcn_readlane((int)seg_hi, l);
+        ++l;
+        const u32 nlo = (u32)__builtin_amdgcn_readlane((int)lo, l), nhi = (u32)__builtin_amdgcn_readlane((int)hi, l);
+        if (idx >= edge) { clo = nlo; chi = nhi; }
     }
-    return c;
+    return __longlong_as_double((long long)(((u64)chi << 32) | clo));
 }
 
-// Select the K largest (value desc, column asc) positive totals of the aggregation table into sel[0 .. need) (graph.h:111-121)
-// and note the smallest of them in ctl->kth_bits.  Returns need = min(K, positive totals); 0xFFFFFFFF: the row must leave
+// Select the K largest (value desc, column asc) positive totals of the aggregation table into sel[0 .. need) (graph.h:111-121),
+// rank them (thread i < need: my_rank = position of sel[i] in the output order) and note the smallest in ctl->kth_bits.  Returns need = min(K, positive totals); 0xFFFFFFFF: the row must leave
 // (more than kSkTie near-ties, or a total outside [2^-63, 2)).  Every thread of the workgroup calls this.
 template <int BLOCK>
-__device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t)
+__device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& my_rank)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 wave = wave_id(), K = (u32)p.K, CA = t.CA;
@@ -472,7 +602,18 @@ __device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t)
         }
         GP_SYNC();
     }
-    if ((u32)tid < need) __hip_atomic_fetch_min(&ctl->kth_bits, t.sel[tid].bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((u32)tid < need) {                                                            // (K <= 128 <= BLOCK)
+        const Cand cd = t.sel[tid];
+        const int ck = (int)((u32)cd.key & p.node_mask);
+        u32 rank = 0;
+        for (u32 j = 0; j < need; ++j) {
+            const Cand o = t.sel[j];
+            const int ok = (int)((u32)o.key & p.node_mask);
+            rank += (o.bits > cd.bits || (o.bits == cd.bits && ok < ck)) ? 1u : 0u;
+        }
+        my_rank = rank;
+        if (rank + 1u == need) ctl->kth_bits = cd.bits;
+    }
     GP_SYNC();
     return need;
 }
@@ -491,29 +632,8 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
     const u32 K = (u32)p.K;
     typedef u32 u4 __attribute__((ext_vector_type(4)));
 
-    // ---- R: the reserve of every node, bounded from above cell by cell (graph.h:90 / :109 summed over the whole log)
-    {
-        const u4 z = {0u, 0u, 0u, 0u};
-        for (u32 i = 4u * (u32)tid; i < t.MR; i += 4u * BLOCK) *(u4*)&t.R[i] = z;
-    }
     for (u32 i = tid; i < 512u; i += BLOCK) t.fine[i] = 0;
     if (tid == 0) { ctl->ovf = 0; ctl->tk_t = 1u; }
-    GP_SYNC();
-    {
-        int l = 0;
-        log_groups<BLOCK>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const u32 ws = g0 + 64u * (u32)q;
-                if (ws >= n_log) break;                                               // wave-uniform
-                const double c = sk_window_coef(ctl, n_levels, ws, (u32)lane, l) * p.sk_rscale;
-                if (k[q] >= 0) {
-                    const u32 add = fx_up(s[q] * c);
-                    if (add) lds_add_u32(&t.R[((u32)k[q] * kSkMulA) >> t.shR], add);
-                }
-            }
-        });
-    }
     GP_SYNC();
     // ---- t_c: the cell value of rank ~ target, off a histogram over (binade, top 4 mantissa bits) of the cells
     for (u32 i = tid; i < t.MR; i += BLOCK) {
@@ -545,7 +665,10 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
     GP_SYNC();
     SKT(ctl, 7);
     u32 t_c = uni(ctl->tk_t);
-    u32 need = 0;
+    u32 need = 0, my_rank = 0;
+    // level boundaries and coefficients of the log, lane-indexed (sk_window_coef)
+    const u32 seg_hi = lane < n_levels ? ctl->seg_off[lane + 1] : 0xFFFFFFFFu;
+    const double cf = lane < n_levels ? ctl->coef[lane] : 0.0;
     bool last = false;                                                                // t_c is a proven bound: what this round selects is final
     for (int round = 0; ; ++round) {
         // One round = every node whose cell reaches t_c, tabled exactly and the K best selected; in P hash partitions when
@@ -563,24 +686,23 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
                 GP_SYNC();
                 if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
-                {
-                    int l = 0;
-                    log_groups<BLOCK>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
+                log_groups<BLOCK>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
+                    u32 cell[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const u32 ws = g0 + 64u * (u32)q;
-                            if (ws >= n_log) break;                                   // wave-uniform
-                            const double c = sk_window_coef(ctl, n_levels, ws, (u32)lane, l);
-                            bool hit = k[q] >= 0 && c != 0.0;
-                            if (hit) hit = t.R[((u32)k[q] * kSkMulA) >> t.shR] >= t_c;
-                            insert_window_asm(t.akeys, t.avals, t.CA, &ctl->ovf, hit ? k[q] : -1, c * s[q], P, part);   // graph.h:90 / :109
-                        }
-                    });
-                }
+                    for (int q = 0; q < 4; ++q) cell[q] = t.R[((u32)max(k[q], 0) * kSkMulA) >> t.shR];      // four lookups in flight
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u32 ws = g0 + 64u * (u32)q;
+                        if (ws >= n_log) break;                                       // wave-uniform
+                        const double c = sk_window_coef(seg_hi, cf, n_levels, ws, (u32)lane);
+                        const bool hit = k[q] >= 0 && c != 0.0 && cell[q] >= t_c;
+                        insert_window_asm(t.akeys, t.avals, t.CA, &ctl->ovf, hit ? k[q] : -1, c * s[q], P, part);   // graph.h:90 / :109
+                    }
+                });
                 GP_SYNC();
                 SKT(ctl, 8);
                 if (uni(ctl->ovf)) { ovf = true; break; }
-                need = sk_select<BLOCK>(p, ctl, t);
+                need = sk_select<BLOCK>(p, ctl, t, my_rank);
                 SKT(ctl, 9);
                 if (need == 0xFFFFFFFFu) { if (tid == 0) ctl->fail = 1; GP_SYNC(); return; }
             }
@@ -604,20 +726,13 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
         }
         if (tid == 0) zstat(ctl, zSweep2, 1);
     }
-    // order the selected entries (value desc, column asc) and write the row
+    // write the row in output order (value desc, column asc)
     const long long out0 = row * (long long)p.K;
-    for (u32 i = tid; i < need; i += BLOCK) {
-        const Cand cd = t.sel[i];
-        const int ck = (int)((u32)cd.key & p.node_mask);
-        u32 rank = 0;
-        for (u32 j = 0; j < need; ++j) {
-            const Cand o = t.sel[j];
-            const int ok = (int)((u32)o.key & p.node_mask);
-            rank += (o.bits > cd.bits || (o.bits == cd.bits && ok < ck)) ? 1u : 0u;
-        }
-        p.out_row[out0 + rank] = seed;                                                // graph.h:122
-        p.out_col[out0 + rank] = ck;                                                  // graph.h:123
-        p.out_val[out0 + rank] = __longlong_as_double((long long)cd.bits);            // graph.h:124
+    if ((u32)tid < need) {
+        const Cand cd = t.sel[tid];
+        p.out_row[out0 + my_rank] = seed;                                             // graph.h:122
+        p.out_col[out0 + my_rank] = (int)((u32)cd.key & p.node_mask);                 // graph.h:123
+        p.out_val[out0 + my_rank] = __longlong_as_double((long long)cd.bits);         // graph.h:124
     }
     if (tid == 0) {
         if (p.out_filled) p.out_filled[row] = (int)need;
@@ -630,7 +745,7 @@ template <int BLOCK>
 __device__ __forceinline__ void sk_wipe(const SkView& w) {
     typedef u32 u4 __attribute__((ext_vector_type(4)));
     const u4 z = {0u, 0u, 0u, 0u};
-    for (u32 i = 4u * threadIdx.x; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
+    for (u32 i = 4u * threadIdx.x; i < w.MR + w.MU; i += 4u * BLOCK) *(u4*)&w.R[i] = z;     // R and U are adjacent
     for (u32 i = threadIdx.x; i < w.CX; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
 }
 template <int BLOCK>
@@ -660,6 +775,9 @@ __device__ __forceinline__ void gfpush_sk_rows()
     const int L = p.n_coef - 1;
     // a level goes straight into the exact table while its edges fit it at <= half load
     const u32 direct_max = CX / 2u;
+    // (a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
+    //  hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax)
+    const double solo_e_bound = p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz;
 
     for (;;) {
         GP_SYNC();
@@ -689,6 +807,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
             u32* bt1 = w.bt2 + (size_t)1 * p.bt_cap;
             if (tid == 0) {
                 if (p.log_cap > 0) { w.log_key[0] = seed_key; w.log_val[0] = 1.0; } else ctl->fail = 1;   // graph.h:90
+                lds_add_u32(&w.R[((u32)seed_key * kSkMulA) >> w.shR], fx_up(ctl->coef[0] * p.sk_rscale));
                 ctl->seg_off[0] = 0;
                 zstat(ctl, zDeg, 1); zstat(ctl, zLevels, 1);
             }
@@ -726,9 +845,10 @@ __device__ __forceinline__ void gfpush_sk_rows()
             }
             n_levels = lvl + 1;
             log_pos += n_rec;
+            const double cs = uni(ctl->coef[lvl]) * p.sk_rscale;                      // reserve-sketch units per unit of share
             SKT(ctl, 6);
             if (last) {
-                phase_sk_stream<BLOCK, 2>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, 0u, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+                phase_sk_stream<BLOCK, 2>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, 0u, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
                 SKT(ctl, 3);
                 break;
             }
@@ -742,17 +862,33 @@ __device__ __forceinline__ void gfpush_sk_rows()
                 const u32 est = (u32)(((u64)n_rec * q) >> 10);
                 if (q != 0 && 5u * est > 3u * CX) P0 = min(64u, (5u * est + 3u * CX - 1u) / (3u * CX));
             }
+            // a small level: one wave does it, the others park at one barrier (phase_sk_solo)
+            const bool solo = p.solo && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&
+                              p.push_cap >= (u64)kSkSoloEdges + 4u && (double)p.bt_cap >= solo_e_bound / (double)(1u << kUnitShift) + 4.0;
+            if (solo) {
+                if (wave_id() == 0)
+                    phase_sk_solo<BLOCK>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, has_dang_cur ? 1u : 0u, dang_cur, seed_key, (u32)(lvl & 1));
+                GP_SYNC();
+                SKT(ctl, 1); SKT_COUNT(ctl, 13, 1);
+            } else {
             SKT2_BEGIN(ctl);
-            if (direct) phase_sk_stream<BLOCK, 1>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
-            else        phase_sk_stream<BLOCK, 0>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+            if (direct) phase_sk_stream<BLOCK, 1>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+            else        phase_sk_stream<BLOCK, 0>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
             SKT2(ctl, 11);
             GP_SYNC();
             SKT2(ctl, 12);
             SKT(ctl, direct ? 1 : 2); SKT_COUNT(ctl, direct ? 13 : 14, 1);
+            }
             // Exact inserts, then SCAN.  A table that overflows is wiped and the level's candidates are walked in hash
             // partitions (q of P, split in two in place), exactly as the general kernel refines its partitions.
             bool u_dirty = !direct, first = true;
             u32 part = 0, np = P0;
+            bool level_done = false;
+            if (solo) {
+                if (!uni(ctl->ovf)) level_done = true;                                // (the wave wrote the next push list and lc[lvl & 1] itself)
+                else { capx = CX; }                                                   // undone: walk the level's log (first pass below sees ctl->ovf)
+            }
+            if (!level_done)
             for (;;) {
                 if (!(first && direct)) {
                     SKT2_BEGIN(ctl);
@@ -818,7 +954,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (tid < 8) ctl->st_row[tid] = 0;
         } else if (tid < 8) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }
         GP_SYNC();
-        sk_wipe<BLOCK>(w);                                                            // TOP-K used the level tables' bytes
+        sk_wipe<BLOCK>(w);                                                            // TOP-K used the level tables' bytes; R is per row
         SKT(ctl, 10);
     }
     GP_SYNC();

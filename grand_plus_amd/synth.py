@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+GEN_VERSION = 1          # bump when csrc/synth_graph.cpp changes what it generates
 
 
 def _lib():
@@ -91,9 +92,14 @@ def shape_csr(name: str):
     s = SHAPES[name]
     cache = os.environ.get("GRANDPLUS_SYNTH_CACHE")
     if cache:
-        fp, fi = (os.path.join(cache, f"{name}_{s.seed}_{k}.npy") for k in ("indptr", "indices"))
+        # every generator parameter is part of the file name (a changed SHAPES entry must not load a stale graph);
+        # GEN_VERSION changes with csrc/synth_graph.cpp
+        tag = f"{name}_n{s.n_nodes}_m{s.samples}_s{s.seed}_o{s.offset}_v{GEN_VERSION}"
+        fp, fi = (os.path.join(cache, f"{tag}_{k}.npy") for k in ("indptr", "indices"))
         if os.path.exists(fp) and os.path.exists(fi):
-            return np.load(fp), np.load(fi)
+            ip, ix = np.load(fp), np.load(fi)
+            if len(ip) == s.n_nodes + 1 and int(ip[-1]) == len(ix):
+                return ip, ix
         indptr, indices = powerlaw_csr(s.n_nodes, s.samples, s.seed, s.offset)
         os.makedirs(cache, exist_ok=True)
         for path, arr in ((fp, indptr), (fi, indices)):

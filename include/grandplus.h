@@ -183,7 +183,7 @@ int gp_reset_stats(gp_graph* g);
  *                      sketch kernel for rmax >= 5e-6 on graphs whose node count exceeds the direct-indexed table
  *   "sk_block_threads" / "sk_lg_mu" / "sk_lg_mr" / "sk_target"   geometry of the sketch kernel (0 = default): threads per
  *                      workgroup (512 = three per CU with 52 KB, 768 = two with 80 KB), log2 cells of the level sketch and
- *                      of the reserve sketch, cell rank of the first TOP-K threshold (default 2 K)
+ *                      of the reserve sketch, cell rank of the first TOP-K threshold (default 4 K)
  *   "diag_flags"      ignored by the product library; the diagnostic build (-DGP_DIAG) skips phases for
  *                      instruction attribution (bit 0: TOP-K) -- its results are then meaningless
  * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.

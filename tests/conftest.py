@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# generated synthetic graphs are kept for the session (the MAG shape is 0.8 GB and several tests use it)
+os.environ.setdefault("GRANDPLUS_SYNTH_CACHE", os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "gp_synth_tests"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -531,18 +531,20 @@ def test_lds_budget_too_small_for_topk_is_rejected():
 
 
 def test_launch_shape_follows_the_recipe():
-    """DESIGN.md section 3, launch shape: three 512-thread workgroups per CU (52 KB of LDS each) for rmax >= 5e-6 and K <= 128, two
-    768-thread workgroups (80 KB) for 128 < K <= 256, one 1024-thread workgroup owning all 160 KB for a small rmax on a graph that
-    is neither tiny nor sparse.  Whatever the shape, the rows are the oracle's."""
+    """DESIGN.md section 3, launch shape.  General kernel (option kernel = 1): three 512-thread workgroups per CU (52 KB of LDS each)
+    for rmax >= 5e-6 and K <= 128, two 768-thread workgroups (80 KB) for 128 < K <= 256, one 1024-thread workgroup owning all
+    160 KB for a small rmax on a graph that is neither tiny nor sparse.  Automatic choice: the sketch kernel (two 768-thread
+    workgroups per CU, 80 KB) for rmax >= 5e-6, K <= 128 on a graph of >= 16 384 nodes.  Whatever runs, the rows are the oracle's."""
     import torch
     from grand_plus_amd import synth
     indptr, indices = synth.shape_csr("small")                      # 100 k nodes, nnz / N = 14: neither tiny nor sparse
     seeds = synth.seeds(len(indptr) - 1, 2048)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     coef = np.array([0.4, 0.3, 0.2, 0.1])
-    for rmax, K, threads, lds, per_cu in ((1e-5, 32, 512, 53248, 3), (1e-5, 200, 768, 81920, 2), (1e-6, 32, 1024, 163840, 1)):
-        got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K)
-        assert (st["block_threads"], st["lds_bytes"]) == (threads, lds), (rmax, K, st["block_threads"], st["lds_bytes"])
+    for opts, rmax, K, kernel, threads, lds, per_cu in (({"kernel": 1}, 1e-5, 32, 1, 512, 53248, 3), ({}, 1e-5, 32, 2, 768, 81920, 2),
+                                                        ({}, 1e-5, 200, 1, 768, 81920, 2), ({}, 1e-6, 32, 1, 1024, 163840, 1)):
+        got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options=opts)
+        assert (st["kernel"], st["block_threads"], st["lds_bytes"]) == (kernel, threads, lds), (rmax, K, st["kernel"], st["block_threads"], st["lds_bytes"])
         assert st["workgroups"] == min(per_cu * cus, len(seeds)) and st["failed_rows"] == 0
         exp, _ = _oracle(indptr, indices, seeds[:256], coef, rmax, K)
         sub = tuple(a[:256 * K] for a in got)

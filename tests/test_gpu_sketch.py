@@ -58,10 +58,10 @@ def test_sketch_kernel_is_the_default_for_filtering_recipes_on_large_graphs():
 
 @pytest.mark.parametrize("opts", [
     {"sk_lg_mu": 8, "sk_lg_mr": 8},                       # 256-cell sketches: nearly every cell collides -- only more exact work
-    {"sk_block_threads": 512, "sk_lg_mu": 13, "sk_lg_mr": 12},     # a big level sketch squeezes the exact table (1 258 slots): partition walks
+    {"sk_block_threads": 512, "sk_lg_mu": 13, "sk_lg_mr": 8},      # a big level sketch squeezes the exact table (1 172 slots): partition walks
     {"sk_target": 1},                                     # first TOP-K threshold at the heaviest cell: more rounds
     {"sk_target": 4096},                                  # ... at (nearly) every cell: the whole support is tabled, in partitions
-    {"sk_block_threads": 512, "sk_lg_mu": 12, "sk_lg_mr": 13},     # a big reserve sketch squeezes the aggregation table
+    {"sk_lg_mr": 9},                                       # a 512-cell reserve sketch: TOP-K tables many more nodes than it needs
 ])
 def test_sketch_kernel_geometries(opts):
     from grand_plus_amd import synth

@@ -5,6 +5,8 @@ OUT=${1:-gpurun_out/fetch_calib}
 export TMPDIR=/tmp
 mkdir -p $OUT
 BIN=$(dirname "$0")/micro/fetch_calib
+SRC=$(dirname "$0")/micro/fetch_calib.hip
+if [ ! -x "$BIN" ] || [ "$SRC" -nt "$BIN" ]; then hipcc --offload-arch=gfx950 -O3 -o "$BIN" "$SRC" || exit 1; fi     # never a checked-in binary
 $BIN > $OUT/requested.txt
 i=0
 for grp in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum" "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do

@@ -227,7 +227,7 @@ enum Counter { kQueue = 0, kQueueRetry, kRetryRows,          // zeroed at every 
                kRetriedTotal,                                 // rows the retry launches have taken since the last reset
                kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
                kGlobalLevels, kFailedRows, kDegLookups,
-               kSkCandEdges, kSkSweep2,                        // sketch kernel (gfpush_sketch.hpp): edges that reached the exact table, rows whose TOP-K needed a second sweep
+               kSkCandEdges, kSkSweep2, kSkSlabFails,                        // sketch kernel (gfpush_sketch.hpp): edges that reached the exact table, rows whose TOP-K needed a second sweep
                kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
                kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
                kDiagX0, kDiagXLast = kDiagX0 + 255,   // GP_DIAG: [0] wave cycles, [1] cycles waves spent at barriers, [2] barriers; [16 + 6*lvl + k] per level:
@@ -1120,6 +1120,14 @@ __device__ __forceinline__ void expand_level(KP p, Ctl* ctl, int* lkeys, double*
 // fixed-stride per-bucket runs of an HBM buffer (flat_edges: one lane per edge), then one clean insert pass per bucket with
 // every lane busy (the level loop of gfpush_rows).
 
+// The row's `filled` word.  With host-resident outputs (gp_gfpush writes the rows straight into pinned host memory) nothing
+// orders it against the row's slot stores -- they leave the chip as independent posted writes, and a system-scope release on
+// gfx950 is a write-back of the whole L2 (measured: +5 ms per 65 536-row launch) -- so the HOST does not trust the order either:
+// it merges a row only once every one of its `filled` slots has changed from the sentinel pattern the slab was left in.
+__device__ __forceinline__ void publish_filled(KP p, long long row, u32 need) {
+    if (threadIdx.x == 0 && p.out_filled) p.out_filled[row] = (int)need;
+}
+
 // ---------------------------------------------------------------- TOP-K
 // Candidates are ordered by the 96-bit composite (value bits, ~column): larger composite =
 // larger value, ties broken towards the SMALLER column id.  Composites are unique per row.
@@ -1470,7 +1478,8 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
     const u32 m = ctl->n_cand;
     const u32 need = m < K ? m : K;                                   // graph.h:113
     if (need == 0 || ctl->fail) {
-        if (tid == 0 && p.out_filled) p.out_filled[row] = 0;
+        // (a row on its way to the retry list publishes nothing: the launch that completes it does)
+        if (tid == 0 && p.out_filled && !(ctl->fail && p.retry_list)) p.out_filled[row] = 0;
         return;
     }
 
@@ -1581,10 +1590,8 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
         p.out_col[out0 + rank] = c.key;                                          // graph.h:123
         p.out_val[out0 + rank] = __longlong_as_double((long long)c.bits);        // graph.h:124
     }
-    if (tid == 0) {
-        if (p.out_filled) p.out_filled[row] = (int)need;
-        stat_add(ctl, sFilled, need);
-    }
+    publish_filled(p, row, need);
+    if (tid == 0) stat_add(ctl, sFilled, need);
     GP_SUB(7);
 }
 

@@ -57,7 +57,7 @@ struct CtlS {
     long long row;
     LevelCtr lc[2];                       // what SCAN of level l produces for level l+1 lives in lc[l & 1] (n_rec: nodes it drained)
     u32 ovf;                              // an exact table / aggregation overflowed
-    u32 fail;                             // the row leaves for the retry list
+    u32 fail;                             // the row leaves for the retry list (1: it outgrew a slab, 3: anything else)
     u32 n_sel, n_tie;                     // select: entries above the K-th bin / inside it
     u32 tk_bin, tk_above, tk_count, tk_total;
     u32 tk_sub, tk_t, tk_wide, tk_pad;
@@ -704,13 +704,13 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 if (uni(ctl->ovf)) { ovf = true; break; }
                 need = sk_select<BLOCK>(p, ctl, t, my_rank);
                 SKT(ctl, 9);
-                if (need == 0xFFFFFFFFu) { if (tid == 0) ctl->fail = 1; GP_SYNC(); return; }
+                if (need == 0xFFFFFFFFu) { if (tid == 0) ctl->fail = 3; GP_SYNC(); return; }
             }
             if (!ovf) break;
             GP_SYNC();
             if (tid == 0) ctl->ovf = 0;
             P *= 2; need = 0;
-            if (P > 64u) { if (tid == 0) ctl->fail = 1; GP_SYNC(); return; }          // (tens of thousands of near-ties: general kernel)
+            if (P > 64u) { if (tid == 0) ctl->fail = 3; GP_SYNC(); return; }          // (tens of thousands of near-ties: general kernel)
             GP_SYNC();
         }
         // Complete?  An unswept node sits in a cell below t_c, so its total * scale < t_c.  With K exact totals selected and
@@ -734,10 +734,8 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
         p.out_col[out0 + my_rank] = (int)((u32)cd.key & p.node_mask);                 // graph.h:123
         p.out_val[out0 + my_rank] = __longlong_as_double((long long)cd.bits);         // graph.h:124
     }
-    if (tid == 0) {
-        if (p.out_filled) p.out_filled[row] = (int)need;
-        zstat(ctl, zFilled, need);
-    }
+    publish_filled(p, row, need);
+    if (tid == 0) zstat(ctl, zFilled, need);
 }
 
 // ---------------------------------------------------------------- the row loop
@@ -835,7 +833,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (n_rec == 0 || uni(ctl->fail)) break;                                  // the frontier died: later levels add nothing
             const bool last = lvl == L;                                               // graph.h:104-110: no push from the last level
             max_e = max(max_e, e_cur);
-            if ((u64)log_pos + n_rec > p.log_cap) { if (tid == 0) ctl->fail = 1; GP_SYNC(); break; }
+            if ((u64)log_pos + n_rec > p.log_cap) { if (tid == 0) ctl->fail = 1; GP_SYNC(); break; }      // (fail = 1: a slab bound, counted for the host's slab sizing; 3: anything else)
             const u32 seg_base = log_pos;
             LevelCtr* nx = &ctl->lc[lvl & 1];
             if (tid == 0) {
@@ -905,7 +903,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
                     if (tid == 0) ctl->ovf = 0;
                     capx = CX;
                     if (np < 0x10000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
-                    if (tid == 0) ctl->fail = 1;
+                    if (tid == 0) ctl->fail = 3;
                     GP_SYNC();
                     break;
                 }
@@ -950,6 +948,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (tid == 0) {
                 const u64 i = __hip_atomic_fetch_add(&p.counters[p.retry_counter], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 p.retry_list[i] = (u32)row;
+                if (ctl->fail != 3) __hip_atomic_fetch_add(&p.counters[kSkSlabFails], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tid < 8) ctl->st_row[tid] = 0;
         } else if (tid < 8) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }

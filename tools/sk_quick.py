@@ -28,4 +28,13 @@ for tag, opts in variants:
         st = g.stats(); ms.append(st["kernel_ms"])
     print(f"{name} {tag:11s}: kernel {st['kernel']} {st['block_threads']}x{st['lds_bytes']} wgs {st['workgroups']} best {min(ms):8.3f} ms median {sorted(ms)[len(ms)//2]:8.3f} -> {S / min(ms) / 1e3:7.3f} M rows/s; "
           f"retried {st['retried_rows']} cand_edges {st['sketch_candidate_edges'] / max(st['edges'], 1):.3f} sweeps2 {st['sketch_second_sweeps']} pushes {st['pushes']} edges {st['edges']} filled {st['filled']} ws {st['workspace_bytes'] / 2**30:.2f} GB", flush=True)
+# the metric's own clock: host buffers in -> host buffers out (gp_gfpush), last variant's options
+import time
+hs = seeds.cpu().numpy().astype(np.int64); K = r.top_k
+row = np.zeros(S * K, np.int32); col = np.zeros(S * K, np.int32); val = np.zeros(S * K)
+ts = []
+for _ in range(5):
+    t = time.perf_counter(); g.gfpush_omp(hs, row, col, val, r.coef(), r.rmax, K); ts.append((time.perf_counter() - t) * 1e3)
+st = g.stats()
+print(f"{name} host API ({tag}): calls {[round(x, 2) for x in ts]} ms, kernel of the last {st['kernel_ms']:.3f} ms -> {S / sorted(ts[1:])[1] / 1e3:.3f} M rows/s", flush=True)
 g.close()

@@ -203,10 +203,12 @@ Slabs slab_sizes(const gp_graph* g, int n_coef, double e_max, double log_records
 }
 
 // The sketch kernel's slab: two push lists, two boundary tables and the per-EDGE reserve log (`log_records` = edges of a row).
-Slabs sk_slab_sizes(const gp_graph* g, double e_max, double log_records) {
+Slabs sk_slab_sizes(const gp_graph* g, double e_max, double log_records, bool at_bound) {
     Slabs sl;
     sl.log_cap = ((u64)(log_records + 64.0) + 3) & ~3ull;
-    sl.push_cap = (u64)(std::min((double)g->n_nodes, std::max(e_max / 4.0, 4096.0)) + 2.0);    // one entry per pushing node: a few per cent of a level's edges (a level with more: general kernel)
+    // one entry per pushing node: a few per cent of a level's edges on the graphs the estimate is for (a level with more: general
+    // kernel); every node of the level when the slabs are sized from the bound anyway (small graphs)
+    sl.push_cap = (u64)(std::min((double)g->n_nodes, at_bound ? e_max : std::max(e_max / 4.0, 4096.0)) + 2.0);
     const double e_bt = std::min(level_edge_bound_of(g), std::max(8.0 * e_max, 1048576.0));
     sl.bt_cap = (((u64)std::max(e_max, e_bt) >> kUnitShift) + 4) & ~1ull;
     return sl;
@@ -251,7 +253,7 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
     Slabs est, skl;
     auto plan = [&]() {
         est = slab_sizes(g, n_coef, e_est, log_est);
-        if (sk_wg > 0) skl = sk_slab_sizes(g, e_est, log_est > 0.0 ? log_est : (double)n_coef * e_est);
+        if (sk_wg > 0) skl = sk_slab_sizes(g, e_est, log_est > 0.0 ? log_est : (double)n_coef * e_est, !(log_est > 0.0));
         return (double)est.per_wg() * n_wg + (sk_wg > 0 ? (double)skl.per_wg() * sk_wg : 0.0);
     };
     while (plan() > 0.5 * (double)budget && e_est > 4096.0) {        // shrink the slabs, not the launch

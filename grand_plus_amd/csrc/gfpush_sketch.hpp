@@ -57,11 +57,12 @@ struct CtlS {
     long long row;
     LevelCtr lc[2];                       // what SCAN of level l produces for level l+1 lives in lc[l & 1] (n_rec: nodes it drained)
     u32 ovf;                              // an exact table / aggregation overflowed
-    u32 fail;                             // the row leaves for the retry list (1: it outgrew a slab, 3: anything else)
+    u32 fail;                             // the row leaves for the retry list (1: it outgrew a slab, 3: the select gave up, 4 / 5: too many partitions)
     u32 n_sel, n_tie;                     // select: entries above the K-th bin / inside it
     u32 tk_bin, tk_above, tk_count, tk_total;
-    u32 tk_sub, tk_t, tk_wide, tk_pad;
+    u32 tk_sub, tk_t, tk_wide, tk_dig;
     u64 kth_bits;                         // smallest selected value (bit pattern)
+    u64 eq_max;                           // select: largest bit pattern inside a crowded bin (== the smallest: one value, ranked by node id)
     u32 bcnt[64];                         // select: binade counters
     u64 st[8], st_row[8];                 // statistics: workgroup totals / the row in flight
     double coef[kSkMaxCoef];
@@ -537,36 +538,51 @@ __device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& m
     const u32 need = min(K, total);
     GP_SYNC();
     if (need == 0) return 0;
-    if (above + cnt_b > need && cnt_b > kSkTie) {
-        // the binade of the K-th value is crowded: split it by the next 8 mantissa bits
+    // While more than kSkTie entries crowd the bucket of the K-th entry, narrow it: 8 more bits of the value at a time (larger
+    // first), then -- a FLAT row: a seed whose neighbour is a hub hands thousands of nodes totals that differ by summation-order
+    // ulps or not at all -- 8 bits of the node id at a time (smaller first: the output order is value desc, column asc).
+    // The bucket is { entries with (bits >> vshift) == vpre and, once vshift == 0, (id >> ishift) == ipre }.
+    u32 vshift = 52; u64 vpre = (u64)(1023u - b_sel);
+    u32 ishift = 8u * (u32)(((int)p.deg_shift + 7) / 8), ipre = 0;
+    while (above + cnt_b > need && cnt_b > kSkTie && (vshift > 0u || ishift > 0u)) {
+        const bool by_value = vshift > 0u;
+        const u32 ds = by_value ? min(8u, vshift) : 8u;
+        const u32 vs_hi = vshift, is_hi = ishift;                                     // the bucket being split
+        if (by_value) vshift -= ds; else ishift -= ds;
         for (u32 i = tid; i < 256u; i += BLOCK) t.fine[i] = 0;
         GP_SYNC();
         for (u32 i = tid; i < CA; i += BLOCK) {
-            if (akeys[i] != kEmpty) {
+            if (akeys[i] != kEmpty && avals[i] > 0.0) {
                 const u64 bits = (u64)__double_as_longlong(avals[i]);
-                if (avals[i] > 0.0 && 1023u - (u32)(bits >> 52) == b_sel) lds_add_u32(&t.fine[(u32)(bits >> 44) & 255u], 1u);
+                const u32 id = (u32)akeys[i] & p.node_mask;
+                if ((bits >> vs_hi) == vpre && (by_value || is_hi >= 32u || (id >> is_hi) == ipre)) {
+                    const u32 dg = by_value ? (u32)(bits >> vshift) & ((1u << ds) - 1u) : (id >> ishift) & 255u;
+                    lds_add_u32(&t.fine[by_value ? 255u - dg : dg], 1u);             // bin order = output order
+                }
             }
         }
         GP_SYNC();
-        if (wave == 0) {                                                              // lane j owns sub-bins [4 j, 4 j + 4)
+        if (wave == 0) {                                                              // lane j owns bins [4 j, 4 j + 4), best first
             u32 cnt[4], sum = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cnt[j] = t.fine[4 * lane + j]; sum += cnt[j]; }
-            const u32 suf = wave_suffix_scan(sum, lane) + above;                      // entries at or above sub-bin 4 * lane
-            const u64 m = __ballot(suf >= need);
-            const int cl = 63 - __builtin_clzll(m | 1ull);
+            const u32 incl = wave_incl_scan_dpp(sum) + above;                         // entries in bins <= 4 lane + 3, and everything above the bucket
+            const u64 m = __ballot(incl >= need);
+            const int cl = m ? __ffsll((long long)m) - 1 : 63;
             if (lane == cl) {
-                u32 acc = suf - sum; int js = 0;
+                u32 acc = incl - sum; int js = 3;
 #pragma unroll
-                for (int j = 3; j >= 0; --j) { if (acc + cnt[j] >= need) { js = j; break; } acc += cnt[j]; }
-                ctl->tk_sub = 4u * (u32)lane + (u32)js; ctl->tk_above = acc; ctl->tk_count = cnt[js];
+                for (int j = 0; j < 4; ++j) { if (acc + cnt[j] >= need) { js = j; break; } acc += cnt[j]; }
+                ctl->tk_dig = 4u * (u32)lane + (u32)js; ctl->tk_above = acc; ctl->tk_count = cnt[js];
             }
         }
         GP_SYNC();
+        const u32 bin = uni(ctl->tk_dig);
         above = uni(ctl->tk_above); cnt_b = uni(ctl->tk_count);
-        if (above + cnt_b > need && cnt_b > kSkTie) return 0xFFFFFFFFu;               // > 256 near-ties
+        if (by_value) vpre = (vpre << ds) | (u64)(255u - bin) ; else ipre = (ipre << 8) | bin;
+        GP_SYNC();
     }
-    const u32 s_sel = uni(ctl->tk_sub);
+    if (above + cnt_b > need && cnt_b > kSkTie) return 0xFFFFFFFFu;                   // (cannot happen: ids are unique)
     // collect: strictly above the K-th bin -> sel; inside it -> tie (all of it goes to sel when it fits exactly)
     const bool take_all = above + cnt_b <= need;
     for (u32 base = 0; base < CA; base += BLOCK) {
@@ -575,9 +591,11 @@ __device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& m
         Cand cd; cd.bits = 0; cd.key = 0; cd.pad = 0;
         if (i < CA && akeys[i] != kEmpty && avals[i] > 0.0) {
             cd.bits = (u64)__double_as_longlong(avals[i]); cd.key = akeys[i];         // (the PACKED key: a merged entry goes back into a table)
-            const u32 e = 1023u - (u32)(cd.bits >> 52), sb = (u32)(cd.bits >> 44) & 255u;
-            const bool in_bin = e == b_sel && (s_sel == 0xFFFFFFFFu || sb == s_sel);
-            const bool over = e < b_sel || (e == b_sel && s_sel != 0xFFFFFFFFu && sb > s_sel);
+            const u32 id = (u32)cd.key & p.node_mask;
+            const u64 vb = cd.bits >> vshift;
+            const bool v_eq = vb == vpre;
+            const bool in_bin = v_eq && (ishift >= 32u || (id >> ishift) == ipre);
+            const bool over = vb > vpre || (v_eq && ishift < 32u && (id >> ishift) < ipre);
             is_sel = over || (in_bin && take_all); is_t = in_bin && !take_all;
         }
         const u32 si = wave_alloc1(&ctl->n_sel, is_sel, lane);
@@ -704,13 +722,13 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 if (uni(ctl->ovf)) { ovf = true; break; }
                 need = sk_select<BLOCK>(p, ctl, t, my_rank);
                 SKT(ctl, 9);
-                if (need == 0xFFFFFFFFu) { if (tid == 0) ctl->fail = 3; GP_SYNC(); return; }
+                if (need == 0xFFFFFFFFu) { if (tid == 0) ctl->fail = 3; GP_SYNC(); return; }      // (3: the select gave up)
             }
             if (!ovf) break;
             GP_SYNC();
             if (tid == 0) ctl->ovf = 0;
             P *= 2; need = 0;
-            if (P > 64u) { if (tid == 0) ctl->fail = 3; GP_SYNC(); return; }          // (tens of thousands of near-ties: general kernel)
+            if (P > 64u) { if (tid == 0) ctl->fail = 4; GP_SYNC(); return; }          // (4: tens of thousands of nodes around the K-th value)
             GP_SYNC();
         }
         // Complete?  An unswept node sits in a cell below t_c, so its total * scale < t_c.  With K exact totals selected and
@@ -903,7 +921,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
                     if (tid == 0) ctl->ovf = 0;
                     capx = CX;
                     if (np < 0x10000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
-                    if (tid == 0) ctl->fail = 3;
+                    if (tid == 0) ctl->fail = 5;                                      // (5: a level's candidates in > 65 536 partitions)
                     GP_SYNC();
                     break;
                 }
@@ -948,7 +966,10 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (tid == 0) {
                 const u64 i = __hip_atomic_fetch_add(&p.counters[p.retry_counter], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 p.retry_list[i] = (u32)row;
-                if (ctl->fail != 3) __hip_atomic_fetch_add(&p.counters[kSkSlabFails], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ctl->fail == 1) __hip_atomic_fetch_add(&p.counters[kSkSlabFails], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef GP_SK_TIMING
+                __hip_atomic_fetch_add(&p.counters[kDiag0 + min(ctl->fail, 7u)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // why rows left (diag_sub[1..5])
+#endif
             }
             if (tid < 8) ctl->st_row[tid] = 0;
         } else if (tid < 8) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }

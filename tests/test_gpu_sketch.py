@@ -147,3 +147,19 @@ def test_sketch_kernel_hub_seeds_and_values_outside_the_binades():
     sd = synth.seeds(len(ip) - 1, 96)
     coef = np.array([0.5, 0.25, 0.125, 0.0625]) * 1e-25
     _check(ip, ix, sd, coef, 1e-4, 4, SK, label="sk tiny values")
+
+
+def test_sketch_kernel_flat_rows_are_ranked_by_node_id_in_the_kernel():
+    """A seed whose neighbour is a hub hands thousands of leaves the very same total: more than 256 EQUAL values around the K-th.
+    The select then ranks the bin by node id (radix select) instead of handing the row to the general kernel; the oracle's
+    (K+1)-th value proves the ties."""
+    n_leaf = 5000
+    n = n_leaf + 2
+    rows = [[0, 1], [0, 1] + list(range(2, n))] + [[1, i] for i in range(2, n)]          # 0 - hub 1 - leaves, self-loops everywhere
+    indptr = np.zeros(n + 1, np.int32); indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate([np.array(sorted(r), np.int32) for r in rows])
+    from grand_plus_amd.recipes import make_coef
+    seeds = np.array([0, 2, 3, 1, 4999, 0], np.int32)
+    for K in (32, 8):
+        st = _check(indptr, indices, seeds, make_coef("ppr", 4, 0.2), 2e-5, K, SK, label=f"sk flat rows K{K}")
+        assert st["retried_rows"] == 0, (st["retried_rows"], st["diag_sub"][:8])

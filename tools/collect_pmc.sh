@@ -13,6 +13,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
   i=$((i+1))
-  timeout -k 5 100 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows > $OUT/g$i.log 2>&1
+  timeout -k 5 100 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py --workload $W --prewarm 0 --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows > $OUT/g$i.log 2>&1
   echo "group $i ($grp): rc=$?"
 done

@@ -1,28 +1,33 @@
 #!/usr/bin/env python3
-"""Summarise the counter CSVs written by tools/collect_pmc.sh into one JSON (per-launch means of the
-timed gfpush_kernel launches: the first `--warmup` launches are dropped).
-Usage: python tools/pmc_summary.py <dir> <out.json> [--warmup 2] [--rows 65536]"""
-import argparse, csv, glob, json, os
+"""Summarise the counter CSVs written by tools/collect_pmc.sh into one JSON: per-CALL means over the timed steps of the bench
+command (which runs with --prewarm 0, so its gfpush launches are exactly (warmup + steps) calls; a call is 2 launches of the
+general kernel or 3 with the sketch kernel in front -- all of a call's launches are summed, the first `--warmup` calls dropped).
+Usage: python tools/pmc_summary.py <dir> <out.json> [--warmup 2] [--steps 5] [--rows 65536]"""
+import argparse, csv, glob, json, os, sys
 from collections import defaultdict
 
 ap = argparse.ArgumentParser(); ap.add_argument("dir"); ap.add_argument("out")
-ap.add_argument("--warmup", type=int, default=2); ap.add_argument("--rows", type=int, default=65536)
+ap.add_argument("--warmup", type=int, default=2); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--rows", type=int, default=65536)
 ap.add_argument("--workload", default="mag")
 a = ap.parse_args()
-per = {}
+per = {}; n_avg = {}; kernels = set()
 for f in sorted(glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True)):
     by = defaultdict(lambda: defaultdict(float))          # counter -> dispatch -> value
     for r in csv.DictReader(open(f)):
-        if "gfpush_kernel<" not in r["Kernel_Name"]:
+        if "gfpush_" not in r["Kernel_Name"] or "kernel<" not in r["Kernel_Name"]:
             continue
+        kernels.add(r["Kernel_Name"].split("(")[0])
         by[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     for c, d in by.items():
         vals = [d[k] for k in sorted(d)]
-        # every call is two launches (all workgroups on estimate-sized slabs, then a few workgroups re-running the rows that
-        # outgrew theirs -- normally none): keep the main launches
-        vals = [v for v in vals if v > 0.05 * max(vals)][a.warmup:]
-        if vals:
-            per[c] = sum(vals) / len(vals)
+        calls = a.warmup + a.steps
+        if len(vals) % calls:
+            print(f"{c}: {len(vals)} gfpush launches are not a multiple of {calls} calls -- skipped", file=sys.stderr)
+            continue
+        lpc = len(vals) // calls                          # launches per call
+        timed = vals[a.warmup * lpc:]
+        per[c] = sum(timed) / a.steps
+        n_avg[c] = {"calls": a.steps, "launches_per_call": lpc}
 g = per.get
 d = {}
 if g("TCC_EA0_RDREQ_sum"): d["hbm_read_bytes_raw"] = g("TCC_EA0_RDREQ_sum") * 64
@@ -44,14 +49,12 @@ if g("SQ_WAVE_CYCLES"):
     if g("SQ_WAIT_ANY"): d["wave_wait_fraction"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
     if g("SQ_ACTIVE_INST_ANY"): d["wave_active_fraction"] = g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")
 if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE"): d["lds_bank_conflict_fraction"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
-import hashlib, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_h = hashlib.sha256()
-for _f in ("grand_plus_amd/csrc/gfpush_kernels.hpp", "grand_plus_amd/csrc/gfpush.hip"):
-    _h.update(open(os.path.join(ROOT, _f), "rb").read())
-json.dump({"workload": a.workload, "seeds_per_gpu": a.rows, "kernel_sha16": _h.hexdigest()[:16],
-           "command": "tools/collect_pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows (one pass per group; mean of the 5 timed main launches)",
-           "kernel": "gp::gfpush_kernel", "per_launch": per, "derived": d,
+sys.path.insert(0, ROOT)
+import bench
+json.dump({"workload": a.workload, "seeds_per_gpu": a.rows, "kernel_sha16": bench.kernel_source_sha16(),
+           "command": "tools/collect_pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --prewarm 0 --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows (one pass per group; per-call mean over the 5 timed calls, all launches of a call summed)",
+           "kernels": sorted(kernels), "averaged_over": n_avg, "per_launch": per, "derived": d,
            "note": "hbm_read_bytes_raw = TCC_EA0_RDREQ x 64 B (= FETCH_SIZE); hbm_read_bytes_corrected = TCC_EA0_RDREQ x 128 B: tools/fetch_calib.sh (profiles/r03_fetch_calib.json) shows one request per 128-byte L2 line for every access shape of this kernel (16-B/lane and SoA streams, runs of 4 / 14 / 64 words, single-word gathers). WRITE_SIZE is taken as it reads (exact for 16-B/lane streaming stores per MI355X_MICROARCH.md). Infinity-Cache hits are included in both. SQ_* cycle counters are in quad-cycles; SQ_BUSY_CYCLES is summed over the 32 shader engines."},
           open(a.out, "w"), indent=1)
 print(json.dumps(d, indent=1))

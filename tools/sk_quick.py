@@ -27,7 +27,7 @@ for tag, opts in variants:
         g.reset_stats(); g.gfpush_device(seeds, r.coef(), r.rmax, r.top_k); torch.cuda.synchronize()
         st = g.stats(); ms.append(st["kernel_ms"])
     print(f"{name} {tag:11s}: kernel {st['kernel']} {st['block_threads']}x{st['lds_bytes']} wgs {st['workgroups']} best {min(ms):8.3f} ms median {sorted(ms)[len(ms)//2]:8.3f} -> {S / min(ms) / 1e3:7.3f} M rows/s; "
-          f"retried {st['retried_rows']} cand_edges {st['sketch_candidate_edges'] / max(st['edges'], 1):.3f} sweeps2 {st['sketch_second_sweeps']} pushes {st['pushes']} edges {st['edges']} filled {st['filled']} ws {st['workspace_bytes'] / 2**30:.2f} GB", flush=True)
+          f"retried {st['retried_rows']} cand_edges {st['sketch_candidate_edges'] / max(st['edges'], 1):.3f} sweeps2 {st['sketch_second_sweeps']} pushes {st['pushes']} edges {st['edges']} filled {st['filled']} ws {st['workspace_bytes'] / 2**30:.2f} GB handed back why {st['diag_sub'][1:6]}", flush=True)
 # the metric's own clock: host buffers in -> host buffers out (gp_gfpush), last variant's options
 import time
 hs = seeds.cpu().numpy().astype(np.int64); K = r.top_k

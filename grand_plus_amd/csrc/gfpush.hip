@@ -95,7 +95,7 @@ struct gp_graph {
     int lds_pad = 0; int pretouch = 0;                                    // experiment knobs: extra dynamic LDS per workgroup that the tables do not use (forces fewer workgroups per CU); memset the workspace when it is allocated
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
     int kernel = 0;                                                        // option: 0 = choose per call, 1 = general kernel, 2 = sketch kernel whenever the call allows it
-    int sk_block = 0, sk_lg_mu = 0, sk_lg_mr = 0, sk_target = 0;           // options: geometry of the sketch kernel (0 = default)
+    int sk_block = 0, sk_lg_mu = 0, sk_lg_mr = 0, sk_target = 0, sk_direct_max = 0;   // options: geometry of the sketch kernel (0 = default)
     int est_kind = 0; int last_kind = 1;                                   // which kernel the running estimate / the last call belongs to
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
@@ -605,6 +605,9 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "sk_lg_mu" || k == "sk_lg_mr") {
         if (value != 0 && (value < 8 || value > 14)) return fail(GP_ERR_INVALID_ARG, "%s must be 0 or in [8, 14]", key);
         (k == "sk_lg_mu" ? g->sk_lg_mu : g->sk_lg_mr) = (int)value;
+    } else if (k == "sk_direct_max") {
+        if (value < 0 || value > (1 << 20)) return fail(GP_ERR_INVALID_ARG, "sk_direct_max must be in [0, 2^20]");
+        g->sk_direct_max = (int)value;          // levels of up to this many edges insert straight into the exact table (0 = half its slots)
     } else if (k == "sk_target") {
         if (value < 0 || value > 4096) return fail(GP_ERR_INVALID_ARG, "sk_target must be in [0, 4096]");
         g->sk_target = (int)value;
@@ -697,8 +700,9 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         for (int i = 0; i < n_coef; ++i) { if (coef[i] < 0.0) ok = false; coef_sum += coef[i]; }
         if (!(coef_sum < 1.0e6)) ok = false;
         // automatic: the recipes whose push test filters (rmax >= 5e-6; at 1e-6 and below most of a frontier pushes and the
-        // sketch has nothing to remove) on graphs too large for direct-indexed tables
-        const bool auto_sk = rmax >= 5e-6 && g->n_nodes >= 16384;
+        // sketch has nothing to remove) on large graphs (measured, 65 536 rows: MAG-shape +15 %, Reddit-shape +36 % over the general
+        // kernel; the 19.7 k-node Pubmed graph, where half of a frontier pushes, -18 %)
+        const bool auto_sk = rmax >= 5e-6 && g->n_nodes >= 65536;
         use_sk = ok && (g->kernel == 2 || auto_sk);
     }
 #endif
@@ -860,6 +864,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         kp.retry_list = w.retry_list; kp.retry_counter = kRetryRows;
         kp.sk_lg_mu = sk_lg_mu; kp.sk_lg_mr = sk_lg_mr; kp.sk_cx = sk_cx;
         kp.sk_target = (u32)(g->sk_target > 0 ? g->sk_target : 4 * K);
+        kp.sk_direct_max = g->sk_direct_max > 0 ? (u32)g->sk_direct_max : 0xFFFFFFFFu;
         kp.sk_rscale = 2147483648.0 / std::max(1.0, coef_sum);
         {   // rmax * 2^31 * (1 - 2^-10), rounded DOWN to fp32: cell >= packed degree * this is necessary for r >= rmax * deg
             float t = (float)(rmax * 2147483648.0 * (1.0 - 1.0 / 1024.0));
@@ -1104,7 +1109,7 @@ int replicate_part(gp_graph* g, int d) {
     q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
     q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
     q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges; q->seedrow = src->seedrow; q->solo_levels = src->solo_levels;
-    q->kernel = src->kernel; q->sk_block = src->sk_block; q->sk_lg_mu = src->sk_lg_mu; q->sk_lg_mr = src->sk_lg_mr; q->sk_target = src->sk_target; q->lds_pad = src->lds_pad;
+    q->kernel = src->kernel; q->sk_block = src->sk_block; q->sk_lg_mu = src->sk_lg_mu; q->sk_lg_mr = src->sk_lg_mr; q->sk_target = src->sk_target; q->lds_pad = src->lds_pad; q->sk_direct_max = src->sk_direct_max;
     const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));

@@ -297,7 +297,7 @@ struct KParams {
     // sketch kernel (gfpush_sketch.hpp): log2 cells of the level sketch U and of the reserve sketch R (built by TOP-K in the level
     // tables' bytes), slots of the exact table X, the cell rank TOP-K reads its first threshold at, rmax * 2^31 * (1 - 2^-10)
     // rounded down (the push bound in sketch units per unit of packed degree), the reserve-sketch scale 2^31 / max(1, sum of coef)
-    u32 sk_lg_mu, sk_lg_mr, sk_cx, sk_target; float sk_thr_f; int sk_pad; double sk_rscale;
+    u32 sk_lg_mu, sk_lg_mr, sk_cx, sk_target; float sk_thr_f; u32 sk_direct_max; double sk_rscale;     // sk_direct_max: levels of up to this many edges skip the sketch
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
 // The launch parameters where the hardware put them: the kernel argument segment (KParams is the kernels' only argument),
@@ -624,7 +624,7 @@ __device__ __forceinline__ bool res_add_hbm(ResRec* tab, u32 cap, int k, double 
 // levels with more than 64 entries, see edge_stream).
 template <class CTL>
 __device__ __forceinline__ void push_alloc(KP p, CTL* ctl, LevelCtr* nx, PushEntry* push, u32* bt_g,
-                                           u32 len, u32 start, double share, int lane)
+                                           u32 len, u32 start, double share, int lane, u32* bt_l = nullptr, u32 bt_l_cap = 0)
 {
     const u64 M = __ballot(len != 0);
     if (M == 0) return;                                                       // wave-uniform: nobody pushes
@@ -640,6 +640,7 @@ __device__ __forceinline__ void push_alloc(KP p, CTL* ctl, LevelCtr* nx, PushEnt
         else ctl->fail = 1;
         for (u32 m = (off + (1u << kUnitShift) - 1u) >> kUnitShift; ((u64)m << kUnitShift) < (u64)off + len; ++m) {   // hubs: one word per 64 edges
             if ((u64)m < p.bt_cap) bt_g[m] = idx; else ctl->fail = 1;
+            if (m < bt_l_cap) bt_l[m] = idx;                                      // (sketch kernel: a copy of the table's head in LDS)
         }
     }
 }

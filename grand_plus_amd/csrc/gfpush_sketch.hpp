@@ -102,6 +102,7 @@ struct SkView {
     CtlS* ctl; u32* R; u32* U; double* xvals; int* xkeys; u32 MU, MR, CX, shU, shR;
     PushEntry* push2; u32* bt2; int* log_key; double* log_val;
     u32 lds_u;                            // byte offset of U inside LDS
+    u32* bt_l; u32 bt_l_cap;              // the head of the current boundary table, in the flag bytes no wave of this block size owns
 };
 __device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
     SkView w;
@@ -113,6 +114,8 @@ __device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
     w.U = lds_at<u32>(w.lds_u);
     w.xvals = lds_at<double>(w.lds_u + 4u * w.MU);
     w.xkeys = lds_at<int>(w.lds_u + 4u * w.MU + 8u * w.CX);
+    w.bt_l = lds_at<u32>(lds0 + (u32)kCtlStruct + 64u * kFlatW * (blockDim.x >> 6));
+    w.bt_l_cap = 16u * kFlatW * (16u - (blockDim.x >> 6));      // 256 words at 768 threads (levels of <= 16 Ki edges), 512 at 512
     const size_t wg = blockIdx.x;
     w.push2   = p.push + wg * 2 * p.push_cap;
     w.bt2     = p.bt + wg * 2 * p.bt_cap;
@@ -172,7 +175,10 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
     const SkView w = sk_view(p, lds0);
     const u32 lane = threadIdx.x & 63u;
     int* lk = w.log_key + seg_base; double* lv = w.log_val + seg_base;
-    edge_stream<BLOCK>(p, w.ctl, w.push2 + (size_t)cur * p.push_cap, w.bt2 + (size_t)cur * p.bt_cap, n_ent, E, false,
+    // (the boundary table's head was also written to LDS by the SCAN that built the push list: one global round trip less in
+    //  front of the first entry load of every level of <= bt_l_cap * 64 edges)
+    const u32* btp = ((E + 63u) >> 6) <= w.bt_l_cap ? (const u32*)w.bt_l : (const u32*)(w.bt2 + (size_t)cur * p.bt_cap);
+    edge_stream<BLOCK>(p, w.ctl, w.push2 + (size_t)cur * p.push_cap, btp, n_ent, E, false,
                        [&](const int (&v)[4], const double (&sh)[4], u32 t0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -336,7 +342,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
                         if (sh != 0.0) { share = sh; len = deg; }
                     }
                 }
-                push_alloc(p, ctl, nx, push, bt_g, len, (u32)ds[v], share, lane);
+                push_alloc(p, ctl, nx, push, bt_g, len, (u32)ds[v], share, lane, w.bt_l, w.bt_l_cap);
             }
         }
         SKT2(ctl, 7);
@@ -455,7 +461,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
                 if (s_ != 0.0) { share = s_; len = deg; }
             }
         }
-        push_alloc(p, ctl, nx, push_nxt, bt_nxt, len, ds, share, (int)lane);
+        push_alloc(p, ctl, nx, push_nxt, bt_nxt, len, ds, share, (int)lane, w.bt_l, w.bt_l_cap);
     }
     st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
     if (lane == 0) {
@@ -790,7 +796,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
     u32 max_e = 0, max_log = 0;
     const int L = p.n_coef - 1;
     // a level goes straight into the exact table while its edges fit it at <= half load
-    const u32 direct_max = CX / 2u;
+    const u32 direct_max = min(p.sk_direct_max, CX / 2u);
     // (a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
     //  hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax)
     const double solo_e_bound = p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz;
@@ -839,7 +845,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
                         }
                         const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
                         if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
-                        else for (u32 m = (u32)tid; m < units; m += BLOCK) bt1[m] = 0u;
+                        else for (u32 m = (u32)tid; m < units; m += BLOCK) { bt1[m] = 0u; if (m < w.bt_l_cap) w.bt_l[m] = 0u; }
                     }
                 }
             }

@@ -180,7 +180,7 @@ int gp_reset_stats(gp_graph* g);
  *                      level start to finish, the others park at one barrier)
  *   "kernel"          0 = choose per call (default), 1 = always the general kernel, 2 = the sketch-filtered kernel whenever
  *                      the call allows it (all coef >= 0, at most 40 levels, K <= 128, rmax > 0).  Automatic choice: the
- *                      sketch kernel for rmax >= 5e-6 on graphs whose node count exceeds the direct-indexed table
+ *                      sketch kernel for rmax >= 5e-6 on graphs of >= 65 536 nodes
  *   "sk_block_threads" / "sk_lg_mu" / "sk_lg_mr" / "sk_target"   geometry of the sketch kernel (0 = default): threads per
  *                      workgroup (512 = three per CU with 52 KB, 768 = two with 80 KB), log2 cells of the level sketch and
  *                      of the reserve sketch, cell rank of the first TOP-K threshold (default 4 K)

@@ -534,7 +534,7 @@ def test_launch_shape_follows_the_recipe():
     """DESIGN.md section 3, launch shape.  General kernel (option kernel = 1): three 512-thread workgroups per CU (52 KB of LDS each)
     for rmax >= 5e-6 and K <= 128, two 768-thread workgroups (80 KB) for 128 < K <= 256, one 1024-thread workgroup owning all
     160 KB for a small rmax on a graph that is neither tiny nor sparse.  Automatic choice: the sketch kernel (two 768-thread
-    workgroups per CU, 80 KB) for rmax >= 5e-6, K <= 128 on a graph of >= 16 384 nodes.  Whatever runs, the rows are the oracle's."""
+    workgroups per CU, 80 KB) for rmax >= 5e-6, K <= 128 on a graph of >= 65 536 nodes.  Whatever runs, the rows are the oracle's."""
     import torch
     from grand_plus_amd import synth
     indptr, indices = synth.shape_csr("small")                      # 100 k nodes, nnz / N = 14: neither tiny nor sparse

@@ -16,6 +16,8 @@ r = RECIPES[rkey]
 seeds = torch.from_numpy(bench.make_seeds(source, len(ip) - 1, S).astype(np.int32)).cuda()
 g = Graph(ip, ix, 0)
 variants = [("general", {"kernel": 1}), ("sketch 768", {"kernel": 2, "sk_block_threads": 768}), ("sketch 512", {"kernel": 2, "sk_block_threads": 512})]
+if os.environ.get("SKQ_ONLY"):
+    variants = [v for v in variants if v[0] in os.environ["SKQ_ONLY"].split(",")]
 for tag, opts in variants:
     for k, v in opts.items():
         g.set_option(k, int(v))
@@ -26,7 +28,7 @@ for tag, opts in variants:
     for _ in range(6):
         g.reset_stats(); g.gfpush_device(seeds, r.coef(), r.rmax, r.top_k); torch.cuda.synchronize()
         st = g.stats(); ms.append(st["kernel_ms"])
-    print(f"{name} {tag:11s}: kernel {st['kernel']} {st['block_threads']}x{st['lds_bytes']} wgs {st['workgroups']} best {min(ms):8.3f} ms median {sorted(ms)[len(ms)//2]:8.3f} -> {S / min(ms) / 1e3:7.3f} M rows/s; "
+    print(f"{name} {tag:11s} {extra if opts['kernel'] == 2 else ''}: kernel {st['kernel']} {st['block_threads']}x{st['lds_bytes']} wgs {st['workgroups']} best {min(ms):8.3f} ms median {sorted(ms)[len(ms)//2]:8.3f} -> {S / min(ms) / 1e3:7.3f} M rows/s; "
           f"retried {st['retried_rows']} cand_edges {st['sketch_candidate_edges'] / max(st['edges'], 1):.3f} sweeps2 {st['sketch_second_sweeps']} pushes {st['pushes']} edges {st['edges']} filled {st['filled']} ws {st['workspace_bytes'] / 2**30:.2f} GB handed back why {st['diag_sub'][1:6]}", flush=True)
 # the metric's own clock: host buffers in -> host buffers out (gp_gfpush), last variant's options
 import time

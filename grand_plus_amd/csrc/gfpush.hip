@@ -96,7 +96,7 @@ struct gp_graph {
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
     int kernel = 0;                                                        // option: 0 = choose per call, 1 = general kernel, 2 = sketch kernel whenever the call allows it
     int sk_block = 0, sk_lg_mu = 0, sk_lg_mr = 0, sk_target = 0, sk_direct_max = 0;   // options: geometry of the sketch kernel (0 = default)
-    int est_kind = 0; int last_kind = 1;                                   // which kernel the running estimate / the last call belongs to
+    int est_kind = 0; int last_kind = 1; bool sk_auto_off = false; double sk_off_rmax = 0.0; int sk_off_n_coef = 0;                                   // which kernel the running estimate / the last call belongs to
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
     double est_rmax = -1.0; int est_n_coef = 0;                            // the call parameters that estimate belongs to
@@ -316,6 +316,12 @@ void grow_estimate(gp_graph* g) {
     if (outgrown > 0.02 * rows) g->est_edges = std::max(g->est_edges, 2.0 * g->cur_e_est);
     else if (outgrown > 0.001 * rows) g->est_edges = std::max(g->est_edges, 1.5 * g->cur_e_est);
     if (outgrown > 0.001 * rows && g->cur_log_est > 0.0) g->est_log = std::max(g->est_log, 1.5 * g->cur_log_est);
+    // the automatic choice of the sketch kernel is a guess from (rmax, graph size): when a call hands more than 5 % of its rows
+    // back for other reasons than slab size -- each of them runs twice, the second time on an eighth of the chip -- later calls
+    // of this recipe go to the general kernel
+    if (g->last_kind == 2 && g->kernel == 0 && (double)g->h_counters[kRetryRows] - outgrown > 0.05 * rows) {
+        g->sk_auto_off = true; g->sk_off_rmax = g->est_rmax; g->sk_off_n_coef = g->est_n_coef;
+    }
 }
 
 // Let the degree of every column ride in the spare bits above its id (sign bit stays clear).
@@ -703,7 +709,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         // sketch has nothing to remove) on large graphs (measured, 65 536 rows: MAG-shape +15 %, Reddit-shape +36 % over the general
         // kernel; the 19.7 k-node Pubmed graph, where half of a frontier pushes, -18 %)
         const bool auto_sk = rmax >= 5e-6 && g->n_nodes >= 65536;
-        use_sk = ok && (g->kernel == 2 || auto_sk);
+        use_sk = ok && (g->kernel == 2 || (auto_sk && !(g->sk_auto_off && g->sk_off_rmax == rmax && g->sk_off_n_coef == n_coef)));
     }
 #endif
     int sk_block = 0, sk_lds = 0, sk_wg = 0; u32 sk_lg_mu = 0, sk_lg_mr = 0, sk_cx = 0;

@@ -163,3 +163,45 @@ def test_sketch_kernel_flat_rows_are_ranked_by_node_id_in_the_kernel():
     for K in (32, 8):
         st = _check(indptr, indices, seeds, make_coef("ppr", 4, 0.2), 2e-5, K, SK, label=f"sk flat rows K{K}")
         assert st["retried_rows"] == 0, (st["retried_rows"], st["diag_sub"][:8])
+
+
+def test_sketch_kernel_limits_of_its_domain():
+    """The edges of what the sketch kernel takes: K = 128 (its largest), 40 coefficients (its control block), a threshold at the
+    resolution limit (rmax * 2^31 = 64), and one step beyond each, which the general kernel must take."""
+    from grand_plus_amd import synth
+    indptr, indices = synth.shape_csr("small")
+    seeds = synth.seeds(len(indptr) - 1, 256)
+    coef40 = np.full(40, 1.0 / 40)
+    _check(indptr, indices, seeds, coef40, 2e-5, 128, SK, label="sk K128 L39")
+    _check(indptr, indices, seeds, np.full(41, 1.0 / 41), 2e-5, 16, SK, want_kernel=1)
+    _check(indptr, indices, seeds, coef40[:6] * (40 / 6), 2e-5, 129, SK, want_kernel=1)
+    lim = 64.0 / 2147483648.0
+    _check(indptr, indices, seeds[:48], np.array([0.5, 0.3, 0.2]), lim * 1.0001, 16, SK, label="sk rmax at the resolution limit")
+    _check(indptr, indices, seeds[:48], np.array([0.5, 0.3, 0.2]), lim * 0.99, 16, SK, want_kernel=1)
+
+
+def test_automatic_choice_backs_off_when_the_sketch_kernel_hands_its_rows_back():
+    """Coefficients that put totals above 2.0 (outside the binades the sketch kernel's select counts): under the automatic choice
+    the first call runs every row twice (sketch kernel, then general kernel), later calls of the recipe go to the general kernel
+    directly; a different recipe gets the automatic choice again.  Results equal the oracle's either way."""
+    from grand_plus_amd import Graph, synth
+    from grand_plus_amd.recipes import RECIPES
+    indptr, indices = synth.shape_csr("small")
+    seeds = synth.seeds(len(indptr) - 1, 512)
+    coef, rmax, K = np.array([3.0, 1.0, 0.5]), 1e-5, 16
+    exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
+    g = Graph(indptr, indices, 0)
+    kernels = []
+    for _ in range(3):
+        row = np.zeros(len(seeds) * K, np.int32); col = np.zeros_like(row); val = np.zeros(len(seeds) * K, np.float64)
+        g.gfpush_omp(seeds, row, col, val, coef, rmax, K)
+        st = g.stats()
+        kernels.append((st["kernel"], st["retried_rows"]))
+        _assert_parity(seeds, K, (row, col, val), exp, label=f"back-off call {len(kernels)}")
+        assert (st["pushes"], st["edges"], st["filled"]) == (ost["pushes"], ost["edges"], ost["filled"])
+    assert kernels[0] == (2, len(seeds)) and kernels[1][0] == 1 and kernels[2][0] == 1, kernels
+    r = RECIPES[("mag", "ppr")]
+    row = np.zeros(len(seeds) * r.top_k, np.int32); col = np.zeros_like(row); val = np.zeros(len(seeds) * r.top_k, np.float64)
+    g.gfpush_omp(seeds, row, col, val, r.coef(), r.rmax, r.top_k)
+    assert g.stats()["kernel"] == 2
+    g.close()

@@ -60,9 +60,8 @@ struct CtlS {
     u32 fail;                             // the row leaves for the retry list (1: it outgrew a slab, 3: the select gave up, 4 / 5: too many partitions)
     u32 n_sel, n_tie;                     // select: entries above the K-th bin / inside it
     u32 tk_bin, tk_above, tk_count, tk_total;
-    u32 tk_sub, tk_t, tk_wide, tk_dig;
+    u32 tk_t, tk_wide, tk_dig;
     u64 kth_bits;                         // smallest selected value (bit pattern)
-    u64 eq_max;                           // select: largest bit pattern inside a crowded bin (== the smallest: one value, ranked by node id)
     u32 bcnt[64];                         // select: binade counters
     u64 st[8], st_row[8];                 // statistics: workgroup totals / the row in flight
     double coef[kSkMaxCoef];
@@ -536,7 +535,7 @@ __device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& m
         const u32 want = min(K, total);
         const u64 mk = __ballot(incl >= want && want != 0u);
         const int bl = mk ? __ffsll((long long)mk) - 1 : 63;
-        if (lane == bl) { ctl->tk_bin = (u32)bl; ctl->tk_above = incl - cn; ctl->tk_count = cn; ctl->tk_total = total; ctl->tk_sub = 0xFFFFFFFFu; }
+        if (lane == bl) { ctl->tk_bin = (u32)bl; ctl->tk_above = incl - cn; ctl->tk_count = cn; ctl->tk_total = total; }
     }
     GP_SYNC();
     const u32 total = uni(ctl->tk_total), b_sel = uni(ctl->tk_bin);

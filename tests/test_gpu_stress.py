@@ -2,6 +2,8 @@
 (tie-aware) every time, and the oracle's rows on a sample.  Round 3 shipped -- and fixed -- a data race that faulted the GPU in
 3 of 6 Reddit-shape runs (a one-wave level running ahead of the waves that still read a shared control word); one pass of a parity
 test would not have caught it.  Both kernels, default launch shapes, one-wave levels and the seed-row shortcut on."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,8 +11,8 @@ from test_gpu_parity import _assert_parity, _oracle
 
 pytestmark = pytest.mark.gpu
 
-REPS = 6
-ROWS = 16384
+REPS = int(os.environ.get("GRANDPLUS_STRESS_REPS", "6"))          # (a longer soak: tools/r04_final.sh runs 30 x 65 536 once per round)
+ROWS = int(os.environ.get("GRANDPLUS_STRESS_ROWS", "16384"))
 
 
 @pytest.mark.parametrize("shape,recipe", [("reddit", ("reddit", "avg")), ("mag", ("mag", "ppr"))])

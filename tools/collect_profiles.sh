@@ -12,6 +12,8 @@ cp $(ls -t $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 # 2. PMC passes
 tools/collect_pmc.sh mag $OUT/pmc
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > /dev/null
+# (bench.py reads roofline.traffic from profiles/: put this run's summary there before the bench lines are taken)
+[ -n "$PROFILE_ROUND" ] && cp $OUT/pmc_summary.json profiles/${PROFILE_ROUND}_mag_pmc_summary.json
 # 3. the bench lines of the five BASELINE configurations, CPU baseline included
 python - <<PY
 import json, subprocess, sys

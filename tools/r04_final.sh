@@ -4,7 +4,7 @@ cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
 mkdir -p gpurun_out
 timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 > gpurun_out/gpu_tests.txt
 tail -4 gpurun_out/gpu_tests.txt
-bash tools/collect_profiles.sh r04c > gpurun_out/r04c_collect.log 2>&1
+PROFILE_ROUND=r04 bash tools/collect_profiles.sh r04c > gpurun_out/r04c_collect.log 2>&1
 tail -7 gpurun_out/r04c_collect.log
 GRANDPLUS_LIB=libgrandplus_skt.so timeout 600 python tools/sk_phases.py mag 65536 > gpurun_out/r04c/sk_phases.txt 2>&1
 GRANDPLUS_LIB=libgrandplus_skt.so timeout 600 python tools/sk_phases.py mag 4096 max_workgroups=8 >> gpurun_out/r04c/sk_phases.txt 2>&1

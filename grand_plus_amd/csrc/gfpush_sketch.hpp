@@ -375,6 +375,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
     CtlS* ctl = w.ctl; int* lkeys = w.xkeys; double* lvals = w.xvals;
     const u32 lane = threadIdx.x & 63u;
     const u32 cap = kMinCap;
+    const SerialSection ahead;
     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct;                 // wave 0's flag bytes
     u32* list = (u32*)((unsigned char*)ctl + kCtlStruct + 64 * kFlatW);     // the flag areas of the other waves (>= 257 words): they are parked
     static_assert((BLOCK / 64 - 1) * 64 * kFlatW >= 4 * (kSkSoloEdges + 1), "the claimed-slot list lives in the parked waves' flag bytes");
@@ -529,6 +530,7 @@ __device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& m
     GP_SYNC();
     if (uni(ctl->tk_wide)) return 0xFFFFFFFFu;
     if (wave == 0) {                                                                  // lane = binade, 0 holds the largest values
+        const SerialSection ahead;
         const u32 cn = ctl->bcnt[lane];
         const u32 incl = wave_incl_scan_dpp(cn);
         const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
@@ -668,6 +670,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
     }
     GP_SYNC();
     if (wave == 0) {                                                                  // lane j owns bins [8 j, 8 j + 8)
+        const SerialSection ahead;
         u32 cnt[8], sum = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { cnt[j] = t.fine[8 * lane + j]; sum += cnt[j]; }

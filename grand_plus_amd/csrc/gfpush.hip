@@ -613,7 +613,7 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         (k == "sk_lg_mu" ? g->sk_lg_mu : g->sk_lg_mr) = (int)value;
     } else if (k == "sk_direct_max") {
         if (value < 0 || value > (1 << 20)) return fail(GP_ERR_INVALID_ARG, "sk_direct_max must be in [0, 2^20]");
-        g->sk_direct_max = (int)value;          // levels of up to this many edges insert straight into the exact table (0 = half its slots)
+        g->sk_direct_max = (int)value;          // levels of up to this many edges insert straight into the exact table (0 = three quarters of its slots, the most the kernel allows)
     } else if (k == "sk_target") {
         if (value < 0 || value > 4096) return fail(GP_ERR_INVALID_ARG, "sk_target must be in [0, 4096]");
         g->sk_target = (int)value;

@@ -797,8 +797,9 @@ __device__ __forceinline__ void gfpush_sk_rows()
     const long long n_rows = p.n_seeds;
     u32 max_e = 0, max_log = 0;
     const int L = p.n_coef - 1;
-    // a level goes straight into the exact table while its edges fit it at <= half load
-    const u32 direct_max = min(p.sk_direct_max, CX / 2u);
+    // a level goes straight into the exact table while its edges would fill three quarters of it (its nodes: fewer; cap 1/2 / 0.65 / 0.8 / 1
+    // of the slots measured 23.50 / 23.42 / 23.36 / 23.85 ms)
+    const u32 direct_max = min(p.sk_direct_max, 3u * (CX / 4u));
     // (a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
     //  hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax)
     const double solo_e_bound = p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz;
@@ -878,13 +879,14 @@ __device__ __forceinline__ void gfpush_sk_rows()
             }
             const bool direct = n_rec <= direct_max;
             u32 capx = direct ? min(CX, max(kMinCap, (4u * n_rec + 3u) & ~3u)) : CX;
-            // Partitions planned for <= 0.6 load of the exact table, from the nodes per pushed edge this workgroup's earlier rows
-            // tabled at this level (a long probing chain costs every lane of its wave; an overflowed pass costs a whole pass)
+            // Partitions planned so that the nodes expected in the exact table -- per pushed edge what this workgroup's earlier
+            // rows tabled at this level, x 1.25 -- fit its slots: an overflowed pass costs a whole pass, a planned partition one
+            // too (measured, planning for a load of 0.5 / 0.6 / 0.7 / 0.8 / 1.0 / 1.2: 24.75 / 24.2 / 23.95 / 23.75 / 23.54 / 23.57 ms)
             u32 P0 = 1;
             if (!direct) {
                 const u32 q = uni(ctl->cand_q[lvl]);
                 const u32 est = (u32)(((u64)n_rec * q) >> 10);
-                if (q != 0 && 5u * est > 3u * CX) P0 = min(64u, (5u * est + 3u * CX - 1u) / (3u * CX));
+                if (q != 0 && est > CX) P0 = min(64u, (est + CX - 1u) / CX);
             }
             // a small level: one wave does it, the others park at one barrier (phase_sk_solo)
             const bool solo = p.solo && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&

@@ -718,7 +718,9 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         sk_block = g->sk_block ? g->sk_block : 768;
         sk_lds = sk_block == 512 ? kThreeLds : 80 * 1024;
         sk_lg_mu = (u32)(g->sk_lg_mu ? g->sk_lg_mu : (sk_block == 512 ? 12 : 13));
-        sk_lg_mr = (u32)(g->sk_lg_mr ? g->sk_lg_mr : 11);
+        // the reserve sketch resolves the K-th total when ~4K of its cells are heavy: 2 048 cells for K <= 32 (the MAG recipe: 1 024 / 4 096
+        // cells +4 % / +5 % kernel time), 4 096 beyond (the Reddit recipe, K = 64: -5 %; the exact table pays for them with 680 slots)
+        sk_lg_mr = (u32)(g->sk_lg_mr ? g->sk_lg_mr : (K > 32 && sk_block == 768 ? 12 : 11));
         const int64_t x_bytes = (int64_t)sk_lds - kCtlBytes - (4ll << sk_lg_mu) - (4ll << sk_lg_mr);
         sk_cx = x_bytes > 0 ? (u32)(x_bytes / 12) & ~3u : 0u;
         // the exact table, and the aggregation table TOP-K builds over the level sketch + exact table, need >= kMinCap slots

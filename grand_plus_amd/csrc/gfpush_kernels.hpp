@@ -2165,14 +2165,17 @@ __device__ __forceinline__ void gfpush_rows()
             if (direct) {
                 cap = ((u32)p.n_nodes + 3u) & ~3u;       // slot = node id: one pass, no overflow
             } else if (in_lds) {
-                if (need_t * GP_LOAD_DEN <= (u64)C * GP_LOAD_NUM) {
+                // (planned in DISTINCT targets -- the estimate above applied: citation-style graphs -- the table may be planned full:
+                //  Pubmed -3.5 % kernel time at 1.0 against 0.75; planned in edges, 0.875 / 1.0 cost MAG +8 / +18 %, Reddit +4 / +20 %)
+                const u32 ld_num = need_t != need ? 1u : GP_LOAD_NUM, ld_den = need_t != need ? 1u : GP_LOAD_DEN;
+                if (need_t * ld_den <= (u64)C * ld_num) {
                     cap = min(C, max(kMinCap, ((u32)GP_CAP_MULT * (u32)need_t + 3u) & ~3u));
                 } else if (need_t > (u64)kMaxParts * C) {
                     in_lds = false;                      // more than kMaxParts partitions: the HBM table
                 } else {
                     // target load of a partition: 0.75 of the table counted in EDGES (distinct targets are ~15 % fewer); a partition
                     // that overflows anyway is split in place.  0.55 -> 0.75 saved half a pass on the peak levels of the 80 KB shape (+2 %).
-                    parts = ((u32)need_t * GP_LOAD_DEN + C * GP_LOAD_NUM - 1u) / (C * GP_LOAD_NUM);     // need_t <= 64 C < 2^21: 32-bit arithmetic
+                    parts = ((u32)need_t * ld_den + C * ld_num - 1u) / (C * ld_num);     // need_t <= 64 C < 2^21: 32-bit arithmetic
                     cap = C;
                     if (parts > kMaxParts) in_lds = false;
                 }

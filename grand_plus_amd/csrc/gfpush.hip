@@ -1044,20 +1044,24 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
             if (prefix) first_open = it + 1;
         }
     };
-    auto reset_idle = [&](size_t chunk) {      // a piece of the other slab goes back into the sentinel pattern
-        if (idle_done >= g->out_bytes) return;
-        const size_t n = std::min(chunk, g->out_bytes - idle_done);
-        std::memset(idle + idle_done, 0xFF, n);
-        idle_done += n;
-        if (idle_done >= g->out_bytes) g->h_slab_clean[cur ^ 1] = true;
-    };
+    // The other slab goes back into the sentinel pattern meanwhile, on a thread of its own: at K = 64 a 65 536-row call is 68 MB
+    // to validate and copy plus 68 MB to reset inside 13 ms of kernel time -- more than one core moves on a busy host (the
+    // Reddit line's host clock fell to 0.83 x the device-resident rate on one box with both jobs on this thread).
+    struct Resetter {
+        std::thread t;
+        ~Resetter() { if (t.joinable()) t.join(); }
+    } resetter;
+    if (idle_done < g->out_bytes) {
+        const size_t n_reset = g->out_bytes;
+        resetter.t = std::thread([idle, n_reset]() { std::memset(idle, 0xFF, n_reset); });
+    }
     for (;;) {
         const hipError_t q = hipStreamQuery(s);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }        // gp_get_stats below reports it
         sweep();
-        reset_idle((size_t)2 << 20);
     }
+    if (resetter.t.joinable()) { resetter.t.join(); g->h_slab_clean[cur ^ 1] = true; }
     rc = gp_get_stats(g, nullptr);             // synchronises the stream
     if (rc) return rc;
     // every launch has retired: what is still on its way arrives within microseconds

@@ -130,7 +130,9 @@ int     gp_graph_device(const gp_graph* g);
  * caller-allocated and written IN PLACE at slot it*K+i (graph.h:120); only slots with
  * v > 0 are written (graph.h:121), everything else keeps the caller's contents.  Within a row
  * the filled slots are i = 0..filled-1 ordered by (value desc, column asc) -- the reference
- * leaves that order unspecified (nth_element, graph.h:115).  Synchronous.
+ * leaves that order unspecified (nth_element, graph.h:115).  Synchronous.  The calling thread merges
+ * finished rows into the caller's arrays while the kernels run; one helper thread, joined before the
+ * call returns, resets the pinned slab the next call will use.  No OpenMP, no process-wide settings.
  */
 int gp_gfpush(gp_graph* g,
               const int32_t* seeds, int64_t n_seeds,

@@ -130,7 +130,8 @@ __device__ __forceinline__ u32 fx_up(double x) { return (u32)__builtin_ceil(x); 
 
 // Walks log records [0, n) in groups of 256 (four 64-lane windows), groups dealt to the waves round robin; f(key[4], val[4],
 // first record of the group) runs while the NEXT group's eight loads are in flight.  Lanes past n get key -1 (n >= 1).
-template <int BLOCK, class F>
+// NT: the records are not needed again (TOP-K's sweep) -- the loads carry the non-temporal hint, so the lines leave the L2 first.
+template <int BLOCK, bool NT = false, class F>
 __device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 n, F f)
 {
     constexpr u32 kStride = (BLOCK / 64) * 256u;
@@ -144,7 +145,8 @@ __device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 i = min(g0 + 64u * (u32)q + lane, n - 1u);
-            kn[q] = lk[i]; sn[q] = lv[i];
+            if (NT) { kn[q] = __builtin_nontemporal_load(&lk[i]); sn[q] = __builtin_nontemporal_load(&lv[i]); }
+            else    { kn[q] = lk[i]; sn[q] = lv[i]; }
         }
     };
     load(g);
@@ -183,7 +185,11 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
         for (int q = 0; q < 4; ++q) {
             if (v[q] >= 0) {
                 const u32 li = t0 + 64u * (u32)q + lane;                              // the edge's number inside the level
-                lk[li] = v[q]; lv[li] = sh[q];                                        // graph.h:98 -> one log record per edge
+                // graph.h:98 -> one log record per edge.  Only a sketch level's FILTER reads its records back soon; the others are next
+                // read by TOP-K: non-temporal stores (cache-policy hints, measured on the MAG line: sweep loads -0.3 %, these stores
+                // and the solo / output stores -1 ... -2 %; the same hint on sketch levels' stores, FILTER's loads, CSR columns: +1 ... +3 %)
+                if (MODE != 0) { __builtin_nontemporal_store(v[q], &lk[li]); __builtin_nontemporal_store(sh[q], &lv[li]); }
+                else           { lk[li] = v[q]; lv[li] = sh[q]; }
                 const u32 h = (u32)v[q] * kSkMulA;
                 if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(sh[q] * cs));       // graph.h:90 / :109, as an upper bound
                 if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(sh[q] * 2147483648.0));
@@ -421,7 +427,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
         const double vq = q < 4 ? sh[q] : dang;
         if (kq >= 0) {
             const u32 li = q < 4 ? 64u * (u32)q + lane : E;
-            lk[li] = kq; lv[li] = vq;                                       // graph.h:98 -> one log record per edge
+            __builtin_nontemporal_store(kq, &lk[li]); __builtin_nontemporal_store(vq, &lv[li]);      // graph.h:98 -> one log record per edge (next read by TOP-K)
             if (cs != 0.0) lds_add_u32(&w.R[((u32)kq * kSkMulA) >> w.shR], fx_up(vq * cs));
         }
         u32 slot; int seen;
@@ -712,7 +718,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
                 GP_SYNC();
                 if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
-                log_groups<BLOCK>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
+                log_groups<BLOCK, true>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
                     u32 cell[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) cell[q] = t.R[((u32)max(k[q], 0) * kSkMulA) >> t.shR];      // four lookups in flight
@@ -756,9 +762,9 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
     const long long out0 = row * (long long)p.K;
     if ((u32)tid < need) {
         const Cand cd = t.sel[tid];
-        p.out_row[out0 + my_rank] = seed;                                             // graph.h:122
-        p.out_col[out0 + my_rank] = (int)((u32)cd.key & p.node_mask);                 // graph.h:123
-        p.out_val[out0 + my_rank] = __longlong_as_double((long long)cd.bits);         // graph.h:124
+        __builtin_nontemporal_store(seed, &p.out_row[out0 + my_rank]);                                          // graph.h:122
+        __builtin_nontemporal_store((int)((u32)cd.key & p.node_mask), &p.out_col[out0 + my_rank]);             // graph.h:123
+        __builtin_nontemporal_store(__longlong_as_double((long long)cd.bits), &p.out_val[out0 + my_rank]);     // graph.h:124
     }
     publish_filled(p, row, need);
     if (tid == 0) zstat(ctl, zFilled, need);

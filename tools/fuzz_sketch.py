@@ -2,7 +2,7 @@
 """Time-bounded randomised differential test of the sketch kernel against the CPU oracle on graphs large enough for sketch
 levels, partition walks and partitioned TOP-K rounds: random power-law graphs (65 k - 400 k nodes, average degree 4 - 40),
 random recipes (levels, coefficients, rmax 5e-6 .. 2e-4, K 1 .. 128), random sketch geometries, duplicate and hub seeds.
-Rows tie-aware identical, pushes / edges / filled exactly the oracle's.   Usage: python tools/fuzz_sketch.py [seconds] [first case]"""
+Rows tie-aware identical, pushes / edges / filled exactly the oracle's.   Usage: python tools/fuzz_sketch.py [seconds] [first case]   (FUZZ_KERNEL=1: the general kernel under its launch shapes, rmax down to 1e-6)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -36,6 +36,13 @@ while time.time() - t0 < budget:
     seeds[10:13] = seeds[10]                               # duplicates
     opts = {"kernel": 2}
     g = int(rng.integers(0, 6))
+    if os.environ.get("FUZZ_KERNEL") == "1":               # the general kernel under its launch shapes instead
+        opts = {"kernel": 1}; g = -1
+        shape = int(rng.integers(0, 4))
+        if shape == 1: opts.update(block_threads=768, lds_bytes=81920)
+        if shape == 2: opts.update(block_threads=1024, lds_bytes=163840)
+        if shape == 3: opts.update(block_threads=512, lds_bytes=40960)
+        rmax = float(10.0 ** rng.uniform(np.log10(1e-6), np.log10(2e-4)))
     if g == 1: opts.update(sk_block_threads=512)
     if g == 2: opts.update(sk_lg_mu=int(rng.integers(10, 13)), sk_lg_mr=int(rng.integers(9, 12)))
     if g == 3: opts.update(sk_target=int(rng.choice([1, 8, 64, 1024])))

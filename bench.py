@@ -131,32 +131,48 @@ def next_rows(graph, packed, per, K, n_nodes, nnz, dev):
     out = {}
 
     def timed(fn, iters):
-        for _ in range(2):
+        """min and median of `iters` individually timed calls after three warm-ups (two iterations after two
+        warm-ups once read 3x slow on the driver's box and nothing in the line could say why)."""
+        for _ in range(3):
             fn()
         torch.cuda.synchronize(dev)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+        ms = []
         for _ in range(iters):
-            fn()
-        b.record(); torch.cuda.synchronize(dev)
-        return a.elapsed_time(b) / iters
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize(dev)
+            ms.append(a.elapsed_time(b))
+        ms.sort()
+        return ms[0], ms[len(ms) // 2], ms[-1]
+
+    def clock_mhz():
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import device_probe
+            return round(device_probe.shader_clock_mhz(dev.index or 0), 0)
+        except Exception:                                    # the probe is a tools/ aid: its absence must not cost the line
+            return None
 
     try:
         F, B = 128, min(10000, per)
         X = torch.randn((n_nodes, F), device=dev)
         rows = (torch.arange(B, dtype=torch.int64) * 7919 % per).to(torch.int32).to(dev)
-        ms = timed(lambda: random_prop_rows(X, packed.col, packed.val, packed.filled, K, batch_rows=rows, training=False), 20)
+        out["shader_clock_mhz_before"] = clock_mhz()
+        lo, ms, hi = timed(lambda: random_prop_rows(X, packed.col, packed.val, packed.filled, K, batch_rows=rows, training=False), 20)
         kept = int(packed.filled[rows.long()].sum().item())
         by = aug_bytes(kept, B, F)
-        out["augment"] = {"kernel": "random_prop_rows_kernel", "batch_rows": B, "K": K, "feat_dim": F, "ms": round(ms, 4),
-                          "achieved_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        out["augment"] = {"kernel": "random_prop_rows_kernel", "batch_rows": B, "K": K, "feat_dim": F, "ms": round(ms, 4), "ms_min": round(lo, 4), "ms_max": round(hi, 4),
+                          "iters": 20, "achieved_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                          "anomaly": bool(ms > 1.5 * lo), "parity": "unpinned (torch_scatter is un-vendored: oracle/random_prop_ref.py is this repo's restatement)"}
         Fp, steps = 32, 2
         Xp = X[:, :Fp].contiguous()
         outp = torch.empty_like(Xp)
-        ms = timed(lambda: graph.propagate_features(Xp, "ppr", steps, 0.2, out=outp), 2)
+        lo, ms, hi = timed(lambda: graph.propagate_features(Xp, "ppr", steps, 0.2, out=outp), 10)
         by = (4 * Fp * nnz + 4 * nnz + 12 * n_nodes * Fp) * steps
-        out["propagate"] = {"kernel": "spmm_kernel", "feat_dim": Fp, "steps": steps, "ms_per_step": round(ms / steps, 3),
-                            "achieved_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        out["propagate"] = {"kernel": "spmm_kernel", "feat_dim": Fp, "steps": steps, "ms_per_step": round(ms / steps, 3), "ms_per_step_min": round(lo / steps, 3),
+                            "ms_per_step_max": round(hi / steps, 3), "iters": 10,
+                            "achieved_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "anomaly": bool(ms > 1.5 * lo), "parity": "unpinned (model.py:14 imports the un-vendored torch_scatter: oracle/predict_ref.py is this repo's restatement)"}
+        out["shader_clock_mhz_after"] = clock_mhz()
     except Exception as e:                                   # never lose the headline line to a side measurement
         out["error"] = f"{type(e).__name__}: {e}"
     return out
@@ -212,37 +228,42 @@ def parse_args():
     return ap.parse_args()
 
 
-# Test seam (tests/test_bench_gloo.py): with GRANDPLUS_BENCH_DEVICE=cpu the rank code runs its orchestration -- sharding, warm-up,
-# fences, the gather, the max-over-ranks reductions, the JSON line -- on CPU tensors with the Graph class the TEST injects here.
-# There is no CPU implementation of the path behind it: without an injected class the run stops with an error.
-_GRAPH_FACTORY = None
+class CudaPlatform:
+    """What run_rank needs from the machine: the product Graph class, HIP events on torch's current stream, device handles.
+    tests/test_bench_gloo.py passes its own stand-in to run_rank to drive the rank orchestration on CPU tensors; nothing in
+    this file selects anything else."""
+    name = "cuda"
+
+    @staticmethod
+    def graph_class():
+        from grand_plus_amd import Graph
+        return Graph
+
+    @staticmethod
+    def event():
+        import torch
+        return torch.cuda.Event(enable_timing=True)
+
+    @staticmethod
+    def device(local_rank):
+        import torch
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+
+    @staticmethod
+    def sync(dev):
+        import torch
+        torch.cuda.synchronize(dev)
 
 
-class _HostEvent:
-    """torch.cuda.Event stand-in of the CPU test seam (perf_counter stamps)."""
-    def __init__(self, enable_timing=True):
-        self.t = 0.0
-
-    def record(self):
-        self.t = time.perf_counter()
-
-    def elapsed_time(self, other):
-        return (other.t - self.t) * 1e3
-
-
-def run_rank(args) -> int:
+def run_rank(args, platform=CudaPlatform) -> int:
     import torch
     import torch.distributed as dist
-    from grand_plus_amd import Graph, RECIPES, algorithmic_bytes
+    from grand_plus_amd import RECIPES, algorithmic_bytes
     from grand_plus_amd.sharded import PackedRows, gfpush_sharded
-    cpu_seam = os.environ.get("GRANDPLUS_BENCH_DEVICE") == "cpu"
-    if cpu_seam:
-        if _GRAPH_FACTORY is None:
-            print("[bench] GRANDPLUS_BENCH_DEVICE=cpu is a test seam: there is no CPU path to benchmark", file=sys.stderr)
-            return 3
-        Graph = _GRAPH_FACTORY
-    Event = _HostEvent if cpu_seam else torch.cuda.Event
-    dev_sync = (lambda d: None) if cpu_seam else torch.cuda.synchronize
+    Graph = platform.graph_class()
+    Event = lambda enable_timing=True: platform.event()       # noqa: E731
+    dev_sync = platform.sync
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -272,16 +293,6 @@ def run_rank(args) -> int:
     t0 = time.perf_counter()
     indptr, indices = load_graph(source, threads)
     n_nodes = len(indptr) - 1
-    relabel_inv = None
-    if os.environ.get("GRANDPLUS_EXP_RELABEL"):          # experiment: node ids in order of descending degree
-        deg = np.diff(indptr)
-        perm = np.argsort(-deg, kind="stable")
-        relabel_inv = np.empty(n_nodes, dtype=np.int32); relabel_inv[perm] = np.arange(n_nodes, dtype=np.int32)
-        new_deg = deg[perm]
-        new_indptr = np.zeros(n_nodes + 1, dtype=indptr.dtype); np.cumsum(new_deg, out=new_indptr[1:])
-        src = np.repeat(indptr[perm].astype(np.int64) - new_indptr[:-1].astype(np.int64), new_deg) + np.arange(len(indices), dtype=np.int64)
-        indices = np.ascontiguousarray(relabel_inv[indices[src]]); indptr = new_indptr
-        del src, deg, perm, new_deg
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     try:
@@ -292,9 +303,7 @@ def run_rank(args) -> int:
             dist.destroy_process_group()
         return 3
     t_upload = time.perf_counter() - t0
-    if not cpu_seam:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cpu") if cpu_seam else torch.device("cuda", local_rank)
+    dev = platform.device(local_rank)
     if args.block_threads:
         graph.set_option("block_threads", args.block_threads)
     if args.lds_bytes:
@@ -311,8 +320,6 @@ def run_rank(args) -> int:
     S_step = per * world
     n_steps_total = args.warmup + args.steps
     all_seeds = make_seeds(source, n_nodes, S_step * n_steps_total)
-    if relabel_inv is not None:
-        all_seeds = np.ascontiguousarray(relabel_inv[all_seeds])
     # this rank's shard of every step's batch, resident in HBM before timing starts
     shards = []
     for i in range(n_steps_total):
@@ -395,6 +402,8 @@ def run_rank(args) -> int:
         edges_per_launch = stats["edges"] / args.steps
         edges_per_clk_cu = edges_per_launch / (avg_ms * 1e-3) / SHADER_CLOCK_HZ / N_CUS
         sha = kernel_source_sha16()
+        sk_line = stats.get("kernel") == 2
+        insert_share = stats.get("sketch_candidate_edges", 0) / max(stats["edges"], 1) if sk_line else 1.0
         line = {
             "metric": "propagation-matrix rows/sec (whole node)", "value": round(value, 1), "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": args.warmup + prewarm,
@@ -417,13 +426,14 @@ def run_rank(args) -> int:
                          "bytes_per_row": round(bytes_per_launch / per, 1)},
             # the path is not HBM-bound: second yardstick = residue-table inserts per clock and CU against the
             # LDS-atomic insert rate measured by tools/micro/lds_random.hip (clock taken at its 2.4 GHz maximum)
-            "issue_bound": {"bound": "lds_atomic_insert", "achieved": round(edges_per_clk_cu, 5), "peak": round(LDS_INSERT_PEAK, 3),
-                            "unit": "edges/clk/CU", "frac": round(edges_per_clk_cu / LDS_INSERT_PEAK, 5),
+            "issue_bound": {"bound": "lds_atomic_insert", "achieved": round(edges_per_clk_cu * insert_share, 5), "peak": round(LDS_INSERT_PEAK, 3),
+                            "unit": "table inserts/clk/CU", "frac": round(edges_per_clk_cu * insert_share / LDS_INSERT_PEAK, 5),
+                            "counts": "edges that reach the exact table (sketch kernel: sketch_candidate_edges; the other edges are keyless ds_add_u32)" if sk_line else "every traversed edge",
                             "clock_hz": SHADER_CLOCK_HZ, "source": "tools/micro/lds_random.hip -> profiles/r02_lds_random.txt"},
             "detail": {"pushes_per_row": round(stats["pushes"] / stats["rows"], 1),
                        "edges_per_row": round(stats["edges"] / stats["rows"], 1),
-                       "support_per_row": round(stats["support"] / stats["rows"], 1),
-                       "frontier_per_row": round(stats["frontier"] / stats["rows"], 1),
+                       "support_per_row": None if sk_line else round(stats["support"] / stats["rows"], 1),        # (not counted by the sketch kernel)
+                       "frontier_per_row": None if sk_line else round(stats["frontier"] / stats["rows"], 1),
                        "degree_lookups_per_row": round(stats["degree_lookups"] / stats["rows"], 1),
                        "edge_pushes_per_s_per_gpu": round(stats["edges"] / args.steps / (avg_ms * 1e-3), 0),
                        "lds_levels": stats["lds_levels"], "global_levels": stats["global_levels"],

@@ -27,7 +27,7 @@ EXPORTS = (
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
-    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan",
+    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_graph_acsr",
 )
 
 
@@ -119,6 +119,11 @@ def lib():
     L.gp_propagate_features.argtypes = [vp, vp, ctypes.c_int32, vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, vp]
     L.gp_internal_diag_counters.restype = ctypes.c_int
     L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    try:
+        L.gp_internal_graph_acsr.restype = ctypes.c_int
+        L.gp_internal_graph_acsr.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)]
+    except AttributeError:                  # (an older build loaded through GRANDPLUS_LIB for an A/B run: tests/test_host_logic.py checks the product's exports)
+        pass
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     if L.gp_abi_version() != 3:

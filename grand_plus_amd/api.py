@@ -178,6 +178,20 @@ class Graph:
         _native.raise_for_status(rc)
         return st.as_dict()
 
+    def self_addressed_csr(self):
+        """The sketch kernel's copy of the CSR, as host arrays (tests): (acsr int32[32 * n_units + 1] incl. the sentinel word,
+        node_pos uint32[N + 1], unit_info int32[n_units], unit_bits, deg_sat); None when the graph does not allow the layout."""
+        import numpy as np
+        nu, bits, sat = ctypes.c_int64(), ctypes.c_int(), ctypes.c_uint32()
+        L = _native.lib()
+        _native.raise_for_status(L.gp_internal_graph_acsr(self._h, None, None, None, ctypes.byref(nu), ctypes.byref(bits), ctypes.byref(sat)))
+        if nu.value == 0:
+            return None
+        acsr = np.empty(32 * nu.value + 1, np.int32); pos = np.empty(self.num_nodes + 1, np.uint32); info = np.empty(nu.value, np.int32)
+        _native.raise_for_status(L.gp_internal_graph_acsr(self._h, acsr.ctypes.data_as(ctypes.c_void_p), pos.ctypes.data_as(ctypes.c_void_p),
+                                                          info.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nu), ctypes.byref(bits), ctypes.byref(sat)))
+        return acsr, pos, info, bits.value, sat.value
+
     def diag_counters(self):
         """Extended counters of the diagnostic build (GRANDPLUS_DIAG=1); zeros in the product library."""
         buf = (ctypes.c_int64 * 256)()

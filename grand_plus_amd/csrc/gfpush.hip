@@ -52,7 +52,11 @@ struct Slabs {
     u64 push_cap = 0, resg_cap = 0, log_cap = 0, cand_cap = 0, bucket_cap = 0, bt_cap = 0;
     PushEntry* push = nullptr; ResRec* resg = nullptr; ResRec* bucket = nullptr; u32* bt = nullptr;
     int* log_key = nullptr; double* log_val = nullptr; Cand* cand = nullptr;
-    size_t per_wg() const { return 16 * (size_t)(2 * push_cap + resg_cap + cand_cap + bucket_cap) + 12 * (size_t)log_cap + 8 * (size_t)bt_cap + 64; }
+    // sketch kernel (arch_cap > 0): its log record is (column word, 16-bit pusher number) -- log_val is not allocated -- and every
+    // pusher of the row leaves coef * share in `arch`
+    u64 arch_cap = 0; unsigned short* log_pu = nullptr; double* arch = nullptr;
+    size_t log_bytes() const { return arch_cap ? 6 * (size_t)log_cap + 8 * (size_t)arch_cap : 12 * (size_t)log_cap; }
+    size_t per_wg() const { return 16 * (size_t)(2 * push_cap + resg_cap + cand_cap + bucket_cap) + log_bytes() + 8 * (size_t)bt_cap + 64; }
     size_t carve(char* p, int wgs) {                                   // lays the arrays out at p, returns the bytes used
         n_wg = wgs;
         char* q = p;
@@ -60,14 +64,25 @@ struct Slabs {
         resg = (ResRec*)q;     q += 16 * (size_t)wgs * resg_cap;
         cand = (Cand*)q;       q += 16 * (size_t)wgs * cand_cap;
         bucket = (ResRec*)q;   q += 16 * (size_t)wgs * bucket_cap;
-        log_val = (double*)q;  q += 8 * (size_t)wgs * log_cap;
+        if (arch_cap) { arch = (double*)q; q += 8 * (size_t)wgs * arch_cap; log_val = nullptr; }
+        else          { log_val = (double*)q; q += 8 * (size_t)wgs * log_cap; }
         log_key = (int*)q;     q += 4 * (size_t)wgs * log_cap;
         bt = (u32*)q;          q += 4 * (size_t)wgs * 2 * bt_cap;
+        if (arch_cap) { log_pu = (unsigned short*)q; q += 2 * (size_t)wgs * log_cap; }
         return ((size_t)(q - p) + 255) & ~(size_t)255;
     }
     bool covers(const Slabs& o) const {
+        if (o.n_wg == 0) return true;                                  // nothing is asked for
         return n_wg >= o.n_wg && push_cap >= o.push_cap && resg_cap >= o.resg_cap && log_cap >= o.log_cap &&
-               cand_cap >= o.cand_cap && bucket_cap >= o.bucket_cap && bt_cap >= o.bt_cap;
+               cand_cap >= o.cand_cap && bucket_cap >= o.bucket_cap && bt_cap >= o.bt_cap && arch_cap >= o.arch_cap && (arch_cap != 0) == (o.arch_cap != 0);
+    }
+    // the larger of two layouts of the same kind, field by field (a workspace that has served one recipe keeps serving it
+    // when it is re-allocated for another: calls that alternate between recipes must not re-allocate every time -- ADVICE r4)
+    void widen(const Slabs& o) {
+        if (o.n_wg == 0 || (n_wg != 0 && (arch_cap != 0) != (o.arch_cap != 0))) return;
+        n_wg = std::max(n_wg, o.n_wg); push_cap = std::max(push_cap, o.push_cap); resg_cap = std::max(resg_cap, o.resg_cap);
+        log_cap = std::max(log_cap, o.log_cap); cand_cap = std::max(cand_cap, o.cand_cap); bucket_cap = std::max(bucket_cap, o.bucket_cap);
+        bt_cap = std::max(bt_cap, o.bt_cap); arch_cap = std::max(arch_cap, o.arch_cap);
     }
 };
 
@@ -88,6 +103,11 @@ struct gp_graph {
     int* d_indptr = nullptr; int* d_indices = nullptr;
     int deg_shift = 31; uint32_t node_mask = 0x7FFFFFFFu, deg_sat = 0;   // packed column ids (see pack_degree_kernel)
     bool packed = false; int max_degree_bits = 31;                        // packing happens at the first gfpush call
+    // self-addressed CSR of the sketch kernel (ensure_acsr; built at the first call that kernel takes): rows at 128-byte units,
+    // column word = unit number of the target | min(deg, a_sat) << a_shift
+    int acsr_state = 0;                                                   // 0: not built yet, 1: built, -1: the graph does not allow it (unit numbers leave too few degree bits)
+    int* d_acsr = nullptr; uint32_t* d_node_pos = nullptr; int* d_unit_info = nullptr;
+    int64_t n_units = 0; int a_shift = 31; uint32_t a_mask = 0x7FFFFFFFu, a_sat = 0;
     bool rows_distinct = false;                                           // every CSR row holds strictly increasing column ids
     int num_cus = 0;
     // options
@@ -211,6 +231,10 @@ Slabs sk_slab_sizes(const gp_graph* g, double e_max, double log_records, bool at
     sl.push_cap = (u64)(std::min((double)g->n_nodes, at_bound ? e_max : std::max(e_max / 4.0, 4096.0)) + 2.0);
     const double e_bt = std::min(level_edge_bound_of(g), std::max(8.0 * e_max, 1048576.0));
     sl.bt_cap = (((u64)std::max(e_max, e_bt) >> kUnitShift) + 4) & ~1ull;
+    // one coef * share per pusher of the ROW (and per level one for the mass dangling nodes return): a few per cent of its edges
+    // where this kernel is chosen; pusher numbers are 16 bits in the log, a row with more goes to the general kernel
+    sl.arch_cap = (u64)std::min((double)kSkMaxPushers, std::max(at_bound ? (double)sl.log_cap : (double)sl.log_cap / 4.0, 4096.0));
+    sl.arch_cap = (sl.arch_cap + 3) & ~3ull;
     return sl;
 }
 
@@ -260,6 +284,7 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
         e_est *= 0.75; log_est = std::max(4096.0, 0.75 * (log_est > 0.0 ? log_est : (double)est.log_cap));
     }
     if (plan() > 0.5 * (double)budget) {
+        // (the caller re-plans with the general kernel alone unless option kernel = 2 insists)
         if (sk_wg > 0) return fail(GP_ERR_NOMEM, "workspace_mb too small for the sketch kernel's slabs");
         n_wg = (int)std::max<size_t>(1, budget / 2 / est.per_wg());
     }
@@ -283,9 +308,17 @@ int ensure_workspace(gp_graph* g, int n_coef, double rmax, int n_wg, int64_t n_s
     Workspace& w = g->ws;
     const bool fits = w.base && w.est.covers(est) && w.big.covers(big) && w.skl.covers(skl) && w.retry_cap >= n_seeds;
     if (!fits) {
+        auto bytes_of = [&](const Slabs& a, const Slabs& b, const Slabs& c) {
+            return a.per_wg() * (size_t)a.n_wg + b.per_wg() * (size_t)b.n_wg + c.per_wg() * (size_t)c.n_wg;
+        };
+        if (w.base) {                                                // keep what the previous recipes needed, while both fit the budget
+            Slabs e2 = est, b2 = big, s2 = skl;
+            e2.widen(w.est); b2.widen(w.big); s2.widen(w.skl);
+            n_seeds = std::max<int64_t>(n_seeds, w.retry_cap);
+            if (bytes_of(e2, b2, s2) <= budget) { est = e2; big = b2; skl = s2; }
+        }
         free_workspace(w);
-        const size_t total = est.per_wg() * (size_t)est.n_wg + big.per_wg() * (size_t)big.n_wg + skl.per_wg() * (size_t)skl.n_wg +
-                             8 * (size_t)std::max<int64_t>(n_seeds, 1) + 3 * 4096 + 1024;
+        const size_t total = bytes_of(est, big, skl) + 8 * (size_t)std::max<int64_t>(n_seeds, 1) + 3 * 4096 + 1024;
         hipError_t e = hipMalloc(&w.base, total);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -339,6 +372,99 @@ int ensure_packed(gp_graph* g, hipStream_t s) {
                            (long long)g->nnz, g->deg_shift, g->deg_sat);
         HIP_TRY(hipGetLastError());
     }
+    return GP_OK;
+}
+
+// The self-addressed CSR the sketch kernel runs on (built once per graph, on the device, at the first call that kernel takes).
+// Row u starts at unit node_pos[u] (a unit = 32 column words = one 128-byte line) and owns max(1, ceil(deg / 32)) units; its
+// column words are (unit of the target) | min(deg(target), a_sat) << a_shift, padded with -1; acsr[32 * n_units] is the sentinel
+// word lanes without an edge load.  unit_info[first unit of a row] = its node id; unit_info[second unit] = its degree (so the
+// exact degree of a node whose degree field is saturated is ONE word away from its key whenever a_sat > 32).  Unit numbers grow
+// with node ids: ordering keys orders nodes.
+__global__ void __launch_bounds__(256) acsr_units_kernel(const int* indptr, long long n, u32* units)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u <= n; u += stride) {
+        const u32 d = u < n ? (u32)(indptr[u + 1] - indptr[u]) : 0u;
+        units[u] = u < n ? max(1u, (d + 31u) >> 5) : 0u;
+    }
+}
+// exclusive prefix sum of `units` in place, one 1 024-thread workgroup (n ~ 1e7: a few milliseconds, once per graph)
+__global__ void __launch_bounds__(1024) acsr_scan_kernel(u32* units, long long n1, unsigned long long* total)
+{
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    const long long per = (n1 + 1023) / 1024, lo = per * t < n1 ? per * t : n1, hi = lo + per < n1 ? lo + per : n1;
+    unsigned long long s = 0;
+    for (long long i = lo; i < hi; ++i) s += units[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) { unsigned long long a = 0; for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = a; a += v; } *total = a; }
+    __syncthreads();
+    unsigned long long a = part[t];
+    for (long long i = lo; i < hi; ++i) { const u32 v = units[i]; units[i] = (u32)a; a += v; }
+}
+// one wave per node: column words, padding, unit_info
+__global__ void __launch_bounds__(256) acsr_fill_kernel(const int* indptr, const int* indices, u32 node_mask, long long n, const u32* node_pos,
+                                                        int* acsr, int* unit_info, int a_shift, u32 a_sat)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long u = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < n; u += n_waves) {
+        const int s0 = indptr[u];
+        const u32 deg = (u32)(indptr[u + 1] - s0);
+        const u32 pos = node_pos[u], nu = node_pos[u + 1] - pos;
+        int* row = acsr + ((size_t)pos << 5);
+        for (u32 j = lane; j < (nu << 5); j += 64u) {
+            int word = -1;
+            if (j < deg) {
+                const u32 v = (u32)indices[s0 + j] & node_mask;
+                const u32 dv = (u32)(indptr[v + 1] - indptr[v]);
+                word = (int)(node_pos[v] | (min(dv, a_sat) << a_shift));
+            }
+            row[j] = word;
+        }
+        for (u32 j = lane; j < nu; j += 64u) unit_info[pos + j] = j == 0u ? (int)u : j == 1u ? (int)deg : -1;
+    }
+}
+
+int ensure_acsr(gp_graph* g, hipStream_t s) {
+    if (g->acsr_state != 0) return GP_OK;
+    int rc = ensure_packed(g, s);                              // (the fill reads node ids under node_mask whether or not they are packed)
+    if (rc) return rc;
+    const long long n = g->n_nodes;
+    u32* d_pos = nullptr; unsigned long long* d_total = nullptr;
+    HIP_TRY(hipMalloc(&d_pos, sizeof(u32) * (size_t)(n + 2)));
+    struct Guard { u32* p; unsigned long long* t; ~Guard() { if (p) (void)hipFree(p); if (t) (void)hipFree(t); } } guard{d_pos, nullptr};
+    HIP_TRY(hipMalloc(&d_total, sizeof(unsigned long long)));
+    guard.t = d_total;
+    hipLaunchKernelGGL(acsr_units_kernel, dim3(4096), dim3(256), 0, s, g->d_indptr, n, d_pos);
+    hipLaunchKernelGGL(acsr_scan_kernel, dim3(1), dim3(1024), 0, s, d_pos, n + 1, d_total);
+    HIP_TRY(hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int pos_bits = 1;
+    while (pos_bits < 31 && (1ull << pos_bits) < total + 1) ++pos_bits;
+    const int spare = std::min(31 - pos_bits, g->max_degree_bits);
+    // (32 * units + the sentinel must stay a 31-bit word index; fewer than two degree bits: nothing for the cheap push test to read)
+    if (total == 0 || total >= (1ull << 26) || spare < 2) { g->acsr_state = -1; return GP_OK; }
+    g->n_units = (int64_t)total; g->a_shift = pos_bits; g->a_mask = (1u << pos_bits) - 1u; g->a_sat = (1u << spare) - 1u;
+    if (hipMalloc(&g->d_acsr, sizeof(int) * (((size_t)total << 5) + 32)) != hipSuccess ||
+        hipMalloc(&g->d_unit_info, sizeof(int) * ((size_t)total + 2)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (g->d_acsr) { (void)hipFree(g->d_acsr); g->d_acsr = nullptr; }
+        g->acsr_state = -1;                                    // no room for the second copy: the general kernel runs on the packed one
+        return GP_OK;
+    }
+    HIP_TRY(hipMemsetAsync(g->d_acsr + ((size_t)total << 5), 0xFF, sizeof(int) * 32, s));
+    HIP_TRY(hipMemsetAsync(g->d_unit_info + total, 0xFF, sizeof(int) * 2, s));
+    hipLaunchKernelGGL(acsr_fill_kernel, dim3(8192), dim3(256), 0, s, g->d_indptr, g->d_indices, g->node_mask, n, d_pos,
+                       g->d_acsr, g->d_unit_info, g->a_shift, g->a_sat);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    g->d_node_pos = d_pos; guard.p = nullptr;
+    g->acsr_state = 1;
     return GP_OK;
 }
 
@@ -456,6 +582,22 @@ int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indic
     return GP_OK;
 }
 
+int gp_internal_graph_acsr(gp_graph* g, int32_t* h_acsr, uint32_t* h_node_pos, int32_t* h_unit_info,
+                           int64_t* n_units, int* unit_bits, uint32_t* deg_sat) {
+    if (!g || !n_units || !unit_bits || !deg_sat) return fail(GP_ERR_NULL, "null argument");
+    if (g->multi) g = g->part[0];
+    if (!g) return fail(GP_ERR_NULL, "graph handle has no device CSR");
+    HIP_TRY(hipSetDevice(g->device));
+    int rc = ensure_acsr(g, g->stream);
+    if (rc) return rc;
+    const bool have = g->acsr_state == 1;
+    *n_units = have ? g->n_units : 0; *unit_bits = g->a_shift; *deg_sat = g->a_sat;
+    if (have && h_acsr) HIP_TRY(hipMemcpy(h_acsr, g->d_acsr, sizeof(int) * (((size_t)g->n_units << 5) + 1), hipMemcpyDeviceToHost));
+    if (have && h_node_pos) HIP_TRY(hipMemcpy(h_node_pos, g->d_node_pos, sizeof(uint32_t) * (size_t)(g->n_nodes + 1), hipMemcpyDeviceToHost));
+    if (have && h_unit_info) HIP_TRY(hipMemcpy(h_unit_info, g->d_unit_info, sizeof(int) * (size_t)g->n_units, hipMemcpyDeviceToHost));
+    return GP_OK;
+}
+
 int gp_internal_diag_counters(gp_graph* g, int64_t* out, int n) {
     if (!g || !out) return fail(GP_ERR_NULL, "null argument");
     if (g->launched) { HIP_TRY(hipSetDevice(g->device)); HIP_TRY(hipStreamSynchronize(g->last_stream)); }
@@ -563,6 +705,9 @@ void gp_graph_destroy(gp_graph* g) {
     free_workspace(g->ws);
     if (g->d_indptr) (void)hipFree(g->d_indptr);
     if (g->d_indices) (void)hipFree(g->d_indices);
+    if (g->d_acsr) (void)hipFree(g->d_acsr);
+    if (g->d_node_pos) (void)hipFree(g->d_node_pos);
+    if (g->d_unit_info) (void)hipFree(g->d_unit_info);
     if (g->d_counters) (void)hipFree(g->d_counters);
     if (g->h_counters) (void)hipHostFree(g->h_counters);
     if (g->d_coef) (void)hipFree(g->d_coef);
@@ -710,6 +855,11 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         // kernel; the 19.7 k-node Pubmed graph, where half of a frontier pushes, -18 %)
         const bool auto_sk = rmax >= 5e-6 && g->n_nodes >= 65536;
         use_sk = ok && (g->kernel == 2 || (auto_sk && !(g->sk_auto_off && g->sk_off_rmax == rmax && g->sk_off_n_coef == n_coef)));
+        if (use_sk) {                                      // it runs on the self-addressed CSR (built now if this is the first such call)
+            rc = ensure_acsr(g, s);
+            if (rc) return rc;
+            if (g->acsr_state != 1) use_sk = false;
+        }
     }
 #endif
     int sk_block = 0, sk_lds = 0, sk_wg = 0; u32 sk_lg_mu = 0, sk_lg_mr = 0, sk_cx = 0;
@@ -775,6 +925,10 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         if (use_sk) n_wg = std::min(n_wg, std::max(8, g->num_cus / 2));  // the general kernel only re-runs what the sketch kernel hands back (a per-mille of the call)
         n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(n_wg, n_seeds));
         rc = ensure_workspace(g, n_coef, rmax, n_wg, n_seeds, use_sk ? sk_wg : 0);
+        if (rc == GP_ERR_NOMEM && use_sk && g->kernel != 2) {          // the automatic choice must not fail where the general kernel alone fits
+            use_sk = false; g_last_error.clear();
+            continue;
+        }
         if (rc) return rc;
         if (use_sk) break;
         // the workspace budget could not hold two workgroups per CU: one big workgroup per CU is better than
@@ -799,7 +953,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * kNumCounters, s));
         g->reset_pending = false; g->rows_total = 0;
     } else {
-        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * (kRetryRows2 + 1), s));   // the queue heads and the retry counts
+        HIP_TRY(hipMemsetAsync(g->d_counters, 0, sizeof(u64) * (kSkSlabFails + 1), s));  // the queue heads and the retry counts (per call: ADVICE r4)
         if (g->est_recipe_changed)                                                          // maxima of another recipe must not size this one's slabs
             HIP_TRY(hipMemsetAsync(g->d_counters + kMaxLevelEdges, 0, sizeof(u64) * 2, s));
     }
@@ -824,6 +978,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         kp.bt = sl.bt; kp.bt_cap = sl.bt_cap;
         kp.resg = sl.resg; kp.resg_cap = sl.resg_cap;
         kp.log_key = sl.log_key; kp.log_val = sl.log_val; kp.log_cap = sl.log_cap;
+        kp.log_pu = sl.log_pu; kp.arch = sl.arch; kp.arch_cap = sl.arch_cap;
         kp.cand = sl.cand; kp.cand_cap = sl.cand_cap;
         kp.bucket = sl.bucket; kp.bucket_cap = sl.bucket_cap;
     };
@@ -879,8 +1034,14 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
             while ((double)t > rmax * 2147483648.0 * (1.0 - 1.0 / 1024.0)) t = std::nextafterf(t, 0.0f);
             kp.sk_thr_f = t;
         }
+        // ... on the self-addressed CSR: keys are unit numbers under the packed degree
+        kp.indices = g->d_acsr; kp.nnz = (int)(g->n_units << 5);
+        kp.deg_shift = g->a_shift; kp.node_mask = g->a_mask; kp.deg_sat = g->a_sat;
+        kp.node_pos = g->d_node_pos; kp.unit_info = g->d_unit_info; kp.sk_hub_units = g->a_sat > 32u ? 1u : 0u;
         rc = sk_block == 512 ? launch_sk<512>(kp, sk_wg, sk_lds + g->lds_pad, s) : launch_sk<768>(kp, sk_wg, sk_lds + g->lds_pad, s);
         if (rc) return rc;
+        kp.indices = g->d_indices; kp.nnz = (int)g->nnz;
+        kp.deg_shift = g->deg_shift; kp.node_mask = g->node_mask; kp.deg_sat = g->deg_sat;
         // 2. the general kernel over that list (a quarter of the chip: the list is a per-cent of the call); rows that outgrow
         //    ITS estimate-sized slabs go to retry_list2 ...
         use_slabs(w.est);
@@ -1051,9 +1212,11 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
         std::thread t;
         ~Resetter() { if (t.joinable()) t.join(); }
     } resetter;
+    bool reset_inline = false;
     if (idle_done < g->out_bytes) {
         const size_t n_reset = g->out_bytes;
-        resetter.t = std::thread([idle, n_reset]() { std::memset(idle, 0xFF, n_reset); });
+        try { resetter.t = std::thread([idle, n_reset]() { std::memset(idle, 0xFF, n_reset); }); }
+        catch (...) { reset_inline = true; }                   // no thread to be had: this thread resets the slab behind the merge (no exception may leave the C ABI)
     }
     for (;;) {
         const hipError_t q = hipStreamQuery(s);
@@ -1062,6 +1225,7 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
         sweep();
     }
     if (resetter.t.joinable()) { resetter.t.join(); g->h_slab_clean[cur ^ 1] = true; }
+    else if (reset_inline) { std::memset(idle, 0xFF, g->out_bytes); g->h_slab_clean[cur ^ 1] = true; }
     rc = gp_get_stats(g, nullptr);             // synchronises the stream
     if (rc) return rc;
     // every launch has retired: what is still on its way arrives within microseconds

@@ -119,6 +119,8 @@ constexpr u32    kMaxParts   = 64;      // most hash partitions a level starts w
 #endif
 constexpr u32    kBucketMin  = GP_BUCKET_MIN;       // levels needing at least this many partitions bucket their edges in HBM once
                                         // instead of re-reading and hash-filtering every CSR range once per partition
+constexpr u32    kSkUnitShift = 5;      // sketch kernel: its self-addressed CSR starts every row at a unit of 32 column words (128 bytes)
+constexpr u32    kSkMaxPushers = 65536; // ... and numbers the pushers of a row with 16 bits in its log
 constexpr u32    kMaxProbe   = 24;      // an LDS insert that probes this many slots reports overflow
 constexpr u32    kProbeSpan  = kMaxProbe * (kMaxProbe + 1) / 2;   // furthest a triangular probe sequence can walk (300 slots)
                                         // (recoverable: the level / aggregation is redone in more partitions)
@@ -223,11 +225,12 @@ __device__ __forceinline__ u32 wave_sum32(u32 x) {           // sum over the wav
 
 enum Counter { kQueue = 0, kQueueRetry, kRetryRows,          // zeroed at every call: row queue heads of the two launches, rows handed to the retry launch
                kQueueRetry2, kRetryRows2,                     // ... and of the third launch of a sketch-kernel call (sketch -> general -> general with bound-sized slabs)
+               kSkSlabFails,                                  // ... rows of THIS call that outgrew a sketch-kernel slab (grow_estimate compares it with this call's rows)
                kMaxLevelEdges, kMaxLogRecords,                // observed maxima (atomic max): what the next call's slabs are sized from
                kRetriedTotal,                                 // rows the retry launches have taken since the last reset
                kPushes, kEdges, kFilled, kSupport, kFrontier, kLdsLevels,
                kGlobalLevels, kFailedRows, kDegLookups,
-               kSkCandEdges, kSkSweep2, kSkSlabFails,                        // sketch kernel (gfpush_sketch.hpp): edges that reached the exact table, rows whose TOP-K needed a second sweep
+               kSkCandEdges, kSkSweep2,                       // sketch kernel (gfpush_sketch.hpp): edges that reached the exact table, rows whose TOP-K needed a second sweep
                kTicksScan, kTicksExpand, kTicksTopk, kTicksTotal, kTicksScanHbm, kTicksExpandHbm,
                kDiag0, kDiagLast = kDiag0 + 15,   // GP_DIAG: free-form sub-phase slots (see GP_SUB)   // GP_DIAG builds only (100 MHz ticks, summed over workgroups)
                kDiagX0, kDiagXLast = kDiagX0 + 255,   // GP_DIAG: [0] wave cycles, [1] cycles waves spent at barriers, [2] barriers; [16 + 6*lvl + k] per level:
@@ -298,6 +301,13 @@ struct KParams {
     // tables' bytes), slots of the exact table X, the cell rank TOP-K reads its first threshold at, rmax * 2^31 * (1 - 2^-10)
     // rounded down (the push bound in sketch units per unit of packed degree), the reserve-sketch scale 2^31 / max(1, sum of coef)
     u32 sk_lg_mu, sk_lg_mr, sk_cx, sk_target; float sk_thr_f; u32 sk_direct_max; double sk_rscale;     // sk_direct_max: levels of up to this many edges skip the sketch
+    // ... which runs on the SELF-ADDRESSED CSR (gfpush.hip:ensure_acsr): every row starts at a 128-byte unit, a column word holds
+    // the UNIT NUMBER of its target (and the packed degree above it), so a pushing node's columns are found without indptr.  For
+    // that launch `indices` / `nnz` / `deg_shift` / `node_mask` / `deg_sat` describe that copy (nnz = index of its sentinel word).
+    const u32* node_pos;                  // node -> first unit of its row (seeds)
+    const int* unit_info;                 // first unit of a row -> node id (output columns); second unit of a multi-unit row -> its degree
+    unsigned short* log_pu; double* arch; u64 arch_cap;   // per-workgroup: pusher number of every log record; coef * share of every pusher of the row
+    u32 sk_hub_units; u32 sk_pad;         // 1: deg >= deg_sat implies >= 2 units, the exact degree of a saturated node is unit_info[unit + 1]
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
 // The launch parameters where the hardware put them: the kernel argument segment (KParams is the kernels' only argument),

@@ -1,4 +1,4 @@
-// gfpush_sketch.hpp -- the round-4 GFPush kernel for gfx950: exact residues only where they can matter.
+// gfpush_sketch.hpp -- the sketch-filtered GFPush kernel for gfx950: exact residues only where they can matter.
 //
 // Same contract as gfpush_kernels.hpp (reference precompute/graph.h:73-126, one persistent workgroup per row), different
 // structure.  Two facts about the shipped recipes (rmax >= 5e-6 on large graphs; tools/sim/*.cpp measured them on the
@@ -7,38 +7,45 @@
 //   * Only ~8 % of a level's frontier nodes pass the push test r >= rmax*deg (graph.h:94); the other 92 % only
 //     deposit coef*r into the reserve (graph.h:90) and are dropped.  And the reserve is LINEAR in the pushed shares:
 //     reserve[v] = sum over levels and in-edges of coef[l] * share(u).  So a pushed edge (u -> v) needs an EXACT fp64
-//     accumulator for v only if v may push; everything else is one 12-byte log record per edge.
+//     accumulator for v only if v may push; everything else is one 6-byte log record per edge.
 //   * Whether v may push is decided by a KEYLESS upper bound: the level SKETCH U[h(v)] += ceil(share * 2^31) -- one
 //     fire-and-forget ds_add_u32 per edge, no key, no compare-and-swap, no probing, 4 bytes per cell instead of 12 per
 //     slot.  Collisions only ever ADD, so U[h(v)] * 2^-31 >= r(v), and v can push only if its cell reaches
 //     rmax * min(deg, deg_sat) (the degree rides in the packed column word).  On the MAG shape a 8 192-cell sketch lets
-//     23 % of the edges through to the exact table (the true pushers own 16 %); the peak levels -- 7 400 edges, three
-//     hash-partition passes at 52 KB in the round-3 kernel -- take ONE stream over the CSR plus one over the level's log.
+//     23 % of the edges through to the exact table (the true pushers own 16 %).
+//
+// Round 5 -- bytes and dependent round trips (13.8 x the algorithmic bytes at the fabric, 76 % of what the part streams):
+//   * The kernel runs on the SELF-ADDRESSED CSR (gfpush.hip:ensure_acsr): rows start at 128-byte units and a column word holds
+//     the UNIT NUMBER of its target under the packed degree.  A node that pushes needs no indptr lookup -- its columns start at
+//     unit * 32 and its degree is in its key (the rare saturated degree is one word of unit_info) -- which removes one 128-byte
+//     line per pusher (0.23 MB of a MAG row's 1.6 MB) and the dependent round trip in the middle of every SCAN; a run of <= 32
+//     columns is one line (2 123 lines per MAG row instead of 2 577 + 1 844, tools/sim/layout_sim.cpp).  Unit numbers grow with
+//     node ids, so the output order (value desc, column asc) is decided on keys; the K output columns are translated back.
+//   * The log record is 6 bytes: the packed column word and the 16-bit NUMBER of the pusher inside the row.  Who needs the
+//     fp64 share looks it up in LDS: FILTER in the level's share table S (written by STREAM from the push-list entries its waves
+//     hold anyway; it borrows the tail of the exact table's value array), TOP-K in T = coef * share of every pusher of the row
+//     (8 bytes per pusher in HBM, written by SCAN with the entry; ~1 800 per MAG row, staged in the dead level tables).
+//     Round 4's attempt at 6-byte records lost because the share was then a dependent GLOBAL gather in front of every group.
 //
 // Per level l = 1..L of a row (graph.h:83-110):
-//   STREAM  edge_stream over the push list (one lane per edge, gfpush_kernels.hpp): the packed column word and the
-//           pusher's share go to the reserve LOG at position (level base + edge number) -- no allocation, fully
-//           coalesced --, ceil(share * 2^31) into the level sketch U and ceil(coef[l] * share * scale) into the row's
-//           RESERVE SKETCH R (see TOP-K), both fire-and-forget LDS adds.  Small levels skip U and insert straight into
-//           the exact table.
+//   STREAM  sk_edge_stream over the push list (one lane per edge): the packed column word and the pusher number go to the
+//           reserve LOG at position (level base + edge number) -- no allocation, fully coalesced --, ceil(share * 2^31) into
+//           the level sketch U and ceil(coef[l] * share * scale) into the row's RESERVE SKETCH R (see TOP-K), both
+//           fire-and-forget LDS adds.  Small levels skip U and insert straight into the exact table.
 //   FILTER  re-reads the level's log segment (L2-hot, next group of 256 records in flight while one is processed), looks
 //           every edge's cell up and inserts the edges whose target may push into the exact table X (insert_window_asm:
-//           the round-3 LDS hash insert, fp64 atomic add).  X is planned for <= 0.6 load from the candidates per edge the
-//           workgroup's earlier rows had at that level; more than that is walked in hash partitions.
-//   SCAN    drains X: exact push test with the packed degree, indptr lookup for the nodes that pass, dangling rule
-//           (graph.h:91-93), fp64 division, next push list (push_alloc).  A tenth of the round-3 SCAN's items and no log
-//           append: the records were written per edge by STREAM.
+//           LDS hash insert, fp64 atomic add).  More candidates than X holds are walked in hash partitions.
+//   SCAN    drains X: exact push test with the degree in the key, dangling rule (graph.h:91-93), fp64 division, next push
+//           list (sk_push_alloc) and the pushers' coef * share.
 // TOP-K (graph.h:111-126), with the level tables dead and their LDS free:
 //   R[h(v)] += ceil(coef[level] * share * scale) over every pushed edge is an upper bound on every node's reserve, so the
-//   K largest totals live in heavy cells.  (Building R by one more sweep over the log at TOP-K time instead -- 16 KB more
-//   exact table during the levels -- measured 20 us per MAG row against ~1 us for the adds in STREAM.)  The cell value t_c of rank ~2K is read off a histogram
-//   of R, a second sweep sums (exactly, fp64, keyed table) the records whose cell reaches t_c, and if the K-th largest
-//   exact total tau satisfies tau*scale >= t_c no unswept node can beat it: done (95 % of MAG rows; ~200 nodes tabled
-//   instead of the 12 500 of the support).  Otherwise tau is a proven lower bound and one more sweep with t_c = tau*scale
-//   is complete by construction; when its nodes outgrow the table it runs in hash partitions, each partition's K best
-//   merged into a running list (flat rows: thousands of equal totals).
+//   K largest totals live in heavy cells.  The cell value t_c of rank ~4K is read off a histogram of R, one sweep over the log
+//   sums (exactly, fp64, keyed table) the records whose cell reaches t_c, and if the K-th largest exact total tau satisfies
+//   tau*scale >= t_c no unswept node can beat it: done (95 % of MAG rows; ~500 nodes tabled instead of the 12 500 of the
+//   support).  Otherwise tau is a proven lower bound and one more sweep with t_c = tau*scale is complete by construction;
+//   when its nodes outgrow the table it runs in hash partitions, each partition's K best merged into a running list.
 //
-// What is left over -- a workspace bound, more than 64 partitions, more than 256 near-ties, totals outside [2^-63, 2) --
+// What is left over -- a workspace bound, more than 64 partitions, totals outside [2^-63, 2), more pushers than fit LDS --
 // sends the row to the retry list, and the general kernel (gfpush_retry_kernel) runs it.  Not counted here: frontier /
 // support sizes (no structure sees distinct targets any more); `exact_stats` selects the general kernel.
 #pragma once
@@ -65,7 +72,6 @@ struct CtlS {
     u32 bcnt[64];                         // select: binade counters
     u64 st[8], st_row[8];                 // statistics: workgroup totals / the row in flight
     double coef[kSkMaxCoef];
-    u32 seg_off[kSkMaxCoef + 2];          // first log record of every level; [n_levels] = end of the log
     u32 cand_q[kSkMaxCoef];               // per level: exact-table nodes per pushed edge of this workgroup's earlier rows (x 1.25, in 1/1024)
 #ifdef GP_SK_TIMING
     u64 tacc[16]; u64 tlast;              // -DGP_SK_TIMING: 100 MHz ticks thread 0 spent per phase (flushed to the diag_sub counters)
@@ -96,10 +102,12 @@ __device__ __forceinline__ void zstat(CtlS* ctl, int which, u64 n) {
 }
 
 // LDS of a workgroup: CtlS + the per-wave flag bytes (kCtlBytes, as in the general kernel) | R u32[MR] | U u32[MU] |
-// X values f64[CX] | X keys i32[CX].  TOP-K re-uses U and X as { aggregation values f64[CA] | keys i32[CA] | tie Cand[256] | sel Cand[K] }.
+// X values f64[CX] | X keys i32[CX].  A sketch level whose list holds n pushers uses the first CX - (n + 1) slots of X and keeps the
+// level's SHARE TABLE S f64[n + 1] in the value array behind them ([n]: the mass dangling nodes returned to the seed).
+// TOP-K re-uses U and X as { T f64[pushers of the row] | aggregation values f64[CA] | keys i32[CA] | tie Cand[256] | sel Cand[K] }.
 struct SkView {
     CtlS* ctl; u32* R; u32* U; double* xvals; int* xkeys; u32 MU, MR, CX, shU, shR;
-    PushEntry* push2; u32* bt2; int* log_key; double* log_val;
+    PushEntry* push2; u32* bt2; int* log_key; unsigned short* log_pu; double* arch;
     u32 lds_u;                            // byte offset of U inside LDS
     u32* bt_l; u32 bt_l_cap;              // the head of the current boundary table, in the flag bytes no wave of this block size owns
 };
@@ -119,7 +127,8 @@ __device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
     w.push2   = p.push + wg * 2 * p.push_cap;
     w.bt2     = p.bt + wg * 2 * p.bt_cap;
     w.log_key = p.log_key + wg * p.log_cap;
-    w.log_val = p.log_val + wg * p.log_cap;
+    w.log_pu  = p.log_pu + wg * p.log_cap;
+    w.arch    = p.arch + wg * p.arch_cap;
     return w;
 }
 __device__ __forceinline__ void lds_add_u32(u32* cell, u32 v) {
@@ -128,11 +137,23 @@ __device__ __forceinline__ void lds_add_u32(u32* cell, u32 v) {
 // fixed-point image of a non-negative fp64 quantity, rounded UP: sums of these bound the fp64 sums from above
 __device__ __forceinline__ u32 fx_up(double x) { return (u32)__builtin_ceil(x); }
 
-// Walks log records [0, n) in groups of 256 (four 64-lane windows), groups dealt to the waves round robin; f(key[4], val[4],
+// Exact degree and first column word of the node behind a key of the self-addressed CSR (graph.h:43-45 without indptr): the
+// degree field is exact below its saturation value; a saturated one is read from unit_info (the row's second unit holds it when
+// every saturated row has one, else the node id -> indptr).
+__device__ __forceinline__ u32 sk_degree(KP p, u32 key) {
+    const u32 dq = key >> p.deg_shift;
+    if (dq != p.deg_sat) return dq;
+    const u32 unit = key & p.node_mask;
+    if (p.sk_hub_units) return (u32)p.unit_info[unit + 1u];
+    const int node = p.unit_info[unit];
+    return (u32)(p.indptr[node + 1] - p.indptr[node]);
+}
+
+// Walks log records [0, n) in groups of 256 (four 64-lane windows), groups dealt to the waves round robin; f(key[4], pusher[4],
 // first record of the group) runs while the NEXT group's eight loads are in flight.  Lanes past n get key -1 (n >= 1).
 // NT: the records are not needed again (TOP-K's sweep) -- the loads carry the non-temporal hint, so the lines leave the L2 first.
 template <int BLOCK, bool NT = false, class F>
-__device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 n, F f)
+__device__ __forceinline__ void log_groups(const int* lk, const unsigned short* lp, u32 n, F f)
 {
     constexpr u32 kStride = (BLOCK / 64) * 256u;
     const u32 lane = threadIdx.x & 63u;
@@ -140,94 +161,235 @@ __device__ __forceinline__ void log_groups(const int* lk, const double* lv, u32 
     if (g >= n) return;
     // (every load is unconditional -- a lane past n re-reads the last record and is masked when the group is consumed: a
     //  conditional load merges control flow between issue and use, and the compiler then waits for ALL loads in flight)
-    int kn[4]; double sn[4];
+    int kn[4]; u32 pn[4];
     auto load = [&](u32 g0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 i = min(g0 + 64u * (u32)q + lane, n - 1u);
-            if (NT) { kn[q] = __builtin_nontemporal_load(&lk[i]); sn[q] = __builtin_nontemporal_load(&lv[i]); }
-            else    { kn[q] = lk[i]; sn[q] = lv[i]; }
+            if (NT) { kn[q] = __builtin_nontemporal_load(&lk[i]); pn[q] = __builtin_nontemporal_load(&lp[i]); }
+            else    { kn[q] = lk[i]; pn[q] = lp[i]; }
         }
     };
     load(g);
     for (;;) {
-        int k[4]; double s[4];
+        int k[4]; u32 pu[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const bool in = g + 64u * (u32)q + lane < n; k[q] = in ? kn[q] : -1; s[q] = in ? sn[q] : 0.0; }
+        for (int q = 0; q < 4; ++q) { const bool in = g + 64u * (u32)q + lane < n; k[q] = in ? kn[q] : -1; pu[q] = in ? pn[q] : 0u; }
         const u32 cur = g;
         g += kStride;
         const bool more = g < n;                                      // wave-uniform
         if (more) load(g);
-        f(k, s, cur);
+        f(k, pu, cur);
         if (!more) break;
     }
 }
 
+// ---------------------------------------------------------------- the edge enumeration
+// edge_stream of gfpush_kernels.hpp (one lane per edge, equal EDGE counts per wave, three-stage software pipeline; see there),
+// with two additions made where an edge is matched to its entry (not a register of the pipeline is spent on them): the edge's log
+// record gets its pusher number (pu_base + the owner's index in the push list; lp == nullptr: not wanted), and the entries a wave
+// holds in its lanes leave their share in the level's share table S (S == nullptr: not wanted).
+template <int BLOCK, bool NT, class F>
+__device__ __forceinline__ void sk_edge_stream(KP p, CtlS* ctl, const PushEntry* push, const u32* bt, u32 n_ent, u32 E, double* S,
+                                               unsigned short* lp, u32 pu_base, F f)
+{
+    constexpr u32 kWaves = BLOCK / 64;
+    static_assert(kFlatW == 4, "sk_edge_stream reads the four window flags of a lane as one 32-bit word");
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = wave_id();
+    unsigned char* wscr = (unsigned char*)ctl + kCtlStruct + 64 * kFlatW * wave;
+    const int* indices = p.indices;
+    const u32 sentinel = (u32)p.nnz;
+    const u32 units = (E + (1u << kUnitShift) - 1u) >> kUnitShift;
+    // (ranges are dealt from the last wave down, so that a level of a few units lands on wave 0, 1, ...: the waves that were
+    //  dispatched first win the issue arbitration against younger waves, and a small level is a latency chain of one wave)
+    const u32 slot = kWaves - 1u - wave;
+    const u32 u_lo = (u32)(((u64)slot * units) / kWaves), u_hi = (u32)(((u64)(slot + 1) * units) / kWaves);
+    if (u_lo >= u_hi || n_ent == 0) return;
+    const bool small = n_ent <= 64u;                                           // (wave-uniform) the whole list in one wave
+    u32 btv = 0, bt_first = 0;
+    auto load_bt = [&](u32 step0) {
+        const u32 uj = u_lo + 4u * (step0 + lane);
+        btv = uj < u_hi ? bt[uj] : 0u;
+        bt_first = step0;
+    };
+    if (!small) load_bt(0);
+    PushEntry entn; entn.rel = 0; entn.off = 0; entn.share = 0.0;
+    u32 i0n = 0, t0n = 0, t1n = 0;
+    u32 u_next = u_lo;
+    bool have_ent = true;
+    auto fetch_next = [&](u32 end) {
+        if (end < t1n) { i0n += 63u; t0n = end; }
+        else if (u_next < u_hi) {
+            t0n = u_next << kUnitShift; t1n = min(E, min(u_next + 4u, u_hi) << kUnitShift);
+            if (!small) {
+                const u32 s_no = (u_next - u_lo) >> 2;
+                if (s_no - bt_first >= 64u) load_bt(s_no);
+                i0n = (u32)__builtin_amdgcn_readlane((int)btv, (int)(s_no - bt_first));
+            }
+            u_next += 4u;
+        } else { have_ent = false; return; }
+        if (!small) entn = push[min(i0n + lane, n_ent - 1u)];
+    };
+    if (small) entn = push[min(lane, n_ent - 1u)];
+    fetch_next(0);
+
+    int nc[4] = {-1, -1, -1, -1}; double ns[4] = {0.0, 0.0, 0.0, 0.0};
+    u32 nt0 = 0;
+    bool have_cols = false;
+    do {
+        u32 idx[4]; double sh[4]; u32 end = 0;
+        if (have_ent) {
+            const u32 cnt = min(64u, n_ent - i0n);
+            const u32 off = lane < cnt ? entn.off : 0xFFFFFFFFu;
+            if (S && lane < cnt) S[i0n + lane] = entn.share;                   // (entries at step boundaries are written by both neighbours: same value)
+            end = t1n;
+            if (cnt == 64u && i0n + 64u < n_ent) {
+                const u32 o63 = (u32)__builtin_amdgcn_readlane((int)off, 63);
+                if (o63 < t1n) end = o63;
+            }
+            *(u32*)(wscr + 4 * lane) = 0u;
+            if (off > t0n && off < end) { const u32 pos = off - t0n; wscr[(pos & 63u) * 4u + (pos >> 6)] = 1; }
+            asm volatile("" ::: "memory");
+            const u32 fl = *(const u32*)(wscr + 4 * lane);
+            u32 before = small ? (u32)__popcll(__ballot(off <= t0n)) - 1u : 0u;
+            u32 e[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const bool mine = ((fl >> (8 * w)) & 1u) != 0;
+                const u64 M = __ballot(mine);
+                e[w] = before + lane_prefix(M) + (mine ? 1u : 0u);             // the owning lane
+                before += (u32)__popcll(M);
+            }
+            const u64 sbits = (u64)__double_as_longlong(entn.share);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)entn.rel);
+                const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)(u32)sbits);
+                const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)(u32)(sbits >> 32));
+                const u32 q = t0n + 64u * (u32)w + lane;
+                idx[w] = q < end ? rel_e + q : sentinel;                       // graph.h:97
+                sh[w] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                if (lp && q < end) {                                           // graph.h:98 -> the record's pusher number
+                    const unsigned short pu = (unsigned short)(pu_base + i0n + e[w]);
+                    if (NT) __builtin_nontemporal_store(pu, &lp[q]); else lp[q] = pu;
+                }
+            }
+        }
+        int cc[4]; double cs[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; cs[w] = ns[w]; }
+        const u32 ct0 = nt0;
+        const bool had_cols = have_cols;
+        have_cols = have_ent;
+        if (have_ent) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; ns[w] = sh[w]; }
+            nt0 = t0n;
+            fetch_next(end);
+        }
+        if (had_cols) f(cc, cs, ct0);
+    } while (have_cols);
+}
+
+// Appends the pushing nodes of one wave-step to the next level's push list (push_alloc of gfpush_kernels.hpp) and leaves
+// cnext * share -- what every edge of the entry adds to its target's reserve (graph.h:90) -- at the pusher's number in the row.
+__device__ __forceinline__ void sk_push_alloc(KP p, CtlS* ctl, LevelCtr* nx, PushEntry* push, u32* bt_g, double* arch, u32 pu_next, double cnext,
+                                              u32 len, u32 start, double share, int lane, u32* bt_l, u32 bt_l_cap)
+{
+    const u64 M = __ballot(len != 0);
+    if (M == 0) return;                                                       // wave-uniform: nobody pushes
+    const u32 incl = wave_incl_scan_dpp(len);
+    const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    u64 base = 0;
+    if (lane == 0)
+        base = __hip_atomic_fetch_add(&nx->alloc, ((u64)tot << 32) | (u64)(u32)__popcll(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = uni(base);
+    if (len != 0) {
+        const u32 idx = (u32)base + lane_prefix(M), off = (u32)(base >> 32) + (incl - len);
+        if ((u64)idx < p.push_cap && (u64)pu_next + idx < p.arch_cap) {
+            PushEntry pe; pe.rel = start - off; pe.off = off; pe.share = share; push[idx] = pe;
+            arch[pu_next + idx] = cnext * share;
+        } else ctl->fail = 1;
+        for (u32 m = (off + (1u << kUnitShift) - 1u) >> kUnitShift; ((u64)m << kUnitShift) < (u64)off + len; ++m) {   // hubs: one word per 64 edges
+            if ((u64)m < p.bt_cap) bt_g[m] = idx; else ctl->fail = 1;
+            if (m < bt_l_cap) bt_l[m] = idx;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- STREAM
-// MODE 0: log + reserve sketch + level sketch U.   MODE 1: log + reserve sketch + exact insert into X (small levels).
-// MODE 2: log + reserve sketch (last level).   cs = coef[level] * scale: reserve-sketch units per unit of share.
+// MODE 0: log + reserve sketch + level sketch U + share table.   MODE 1: log + reserve sketch + exact insert into X (small levels).
+// MODE 2: log + reserve sketch (last level).   MODE 3: exact inserts of hash partition `part` of `parts` only (a small level whose
+// table overflowed: its records and sketch adds exist).   cs = coef[level] * scale: reserve-sketch units per unit of share.
 template <int BLOCK, int MODE>
 __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, double cs, u32 capx,
-                                                  u32 has_dang, double dang, int seed_key)
+                                                  u32 has_dang, double dang, int seed_key, u32 pu_base, u32 parts, u32 part)
 {
     KP p = kparams();
     lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs); capx = uni(capx);
-    has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key);
+    has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); pu_base = uni(pu_base); parts = uni(parts); part = uni(part);
     const SkView w = sk_view(p, lds0);
     const u32 lane = threadIdx.x & 63u;
-    int* lk = w.log_key + seg_base; double* lv = w.log_val + seg_base;
+    int* lk = w.log_key + seg_base; unsigned short* lp = w.log_pu + seg_base;
+    double* S = MODE == 0 ? w.xvals + capx : nullptr;
     // (the boundary table's head was also written to LDS by the SCAN that built the push list: one global round trip less in
-    //  front of the first entry load of every level of <= bt_l_cap * 64 edges)
-    const u32* btp = ((E + 63u) >> 6) <= w.bt_l_cap ? (const u32*)w.bt_l : (const u32*)(w.bt2 + (size_t)cur * p.bt_cap);
-    edge_stream<BLOCK>(p, w.ctl, w.push2 + (size_t)cur * p.push_cap, btp, n_ent, E, false,
-                       [&](const int (&v)[4], const double (&sh)[4], u32 t0) {
+    //  front of the first entry load of every level of <= bt_l_cap * 64 edges
+    //  -- but a partition walk (MODE 3) runs after a SCAN has written the NEXT list's table head there)
+    const u32* btp = MODE != 3 && ((E + 63u) >> 6) <= w.bt_l_cap ? (const u32*)w.bt_l : (const u32*)(w.bt2 + (size_t)cur * p.bt_cap);
+    sk_edge_stream<BLOCK, MODE != 0>(p, w.ctl, w.push2 + (size_t)cur * p.push_cap, btp, n_ent, E, S, MODE != 3 ? lp : nullptr, pu_base,
+                                     [&](const int (&v)[4], const double (&sh)[4], u32 t0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (v[q] >= 0) {
+            if (MODE != 3 && v[q] >= 0) {
                 const u32 li = t0 + 64u * (u32)q + lane;                              // the edge's number inside the level
                 // graph.h:98 -> one log record per edge.  Only a sketch level's FILTER reads its records back soon; the others are next
-                // read by TOP-K: non-temporal stores (cache-policy hints, measured on the MAG line: sweep loads -0.3 %, these stores
-                // and the solo / output stores -1 ... -2 %; the same hint on sketch levels' stores, FILTER's loads, CSR columns: +1 ... +3 %)
-                if (MODE != 0) { __builtin_nontemporal_store(v[q], &lk[li]); __builtin_nontemporal_store(sh[q], &lv[li]); }
-                else           { lk[li] = v[q]; lv[li] = sh[q]; }
+                // read by TOP-K: non-temporal stores
+                if (MODE != 0) __builtin_nontemporal_store(v[q], &lk[li]); else lk[li] = v[q];
                 const u32 h = (u32)v[q] * kSkMulA;
                 if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(sh[q] * cs));       // graph.h:90 / :109, as an upper bound
                 if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(sh[q] * 2147483648.0));
             }
-            if (MODE == 1) insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q], 1u, 0u);
+            if (MODE == 1 || MODE == 3) insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q], parts, part);
         }
     });
     if (threadIdx.x == 0 && has_dang) {                                               // graph.h:92: the seed gets the dangling mass
-        lk[E] = seed_key; lv[E] = dang;
-        const u32 h = (u32)seed_key * kSkMulA;
-        if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(dang * cs));
-        if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(dang * 2147483648.0));
-        if (MODE == 1 && !res_add_lds(w.xkeys, w.xvals, capx, seed_key, dang)) w.ctl->ovf = 1;
+        if (MODE != 3) {
+            lk[E] = seed_key; lp[E] = (unsigned short)(pu_base + n_ent);
+            const u32 h = (u32)seed_key * kSkMulA;
+            if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(dang * cs));
+            if (MODE == 0) { lds_add_u32(&w.U[h >> w.shU], fx_up(dang * 2147483648.0)); S[n_ent] = dang; }
+        }
+        if ((MODE == 1 || MODE == 3) && (parts == 1u || slot_of(hash_b((u32)seed_key), parts) == part) &&
+            !res_add_lds(w.xkeys, w.xvals, capx, seed_key, dang)) w.ctl->ovf = 1;
     }
 }
 
 // ---------------------------------------------------------------- FILTER
-// The level's log segment [seg_base, seg_base + n): edges whose target MAY push (its sketch cell reaches rmax * packed degree)
-// go into the exact table.  use_u == 0: every edge does (partition walk of a small level whose table overflowed).
-// parts > 1: only targets of hash partition `part`.
+// The log segment [seg_base, seg_base + n) of a sketch level: edges whose target MAY push (its sketch cell reaches rmax * packed
+// degree) go into the exact table with their pusher's share (S[pusher number - pu_base]).  parts > 1: only targets of hash partition `part`.
 template <int BLOCK>
-__device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n, u32 capx, u32 use_u, u32 parts, u32 part)
+__device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n, u32 capx, u32 pu_base, u32 parts, u32 part)
 {
     KP p = kparams();
-    lds0 = uni(lds0); seg_base = uni(seg_base); n = uni(n); capx = uni(capx); use_u = uni(use_u); parts = uni(parts); part = uni(part);
+    lds0 = uni(lds0); seg_base = uni(seg_base); n = uni(n); capx = uni(capx); pu_base = uni(pu_base); parts = uni(parts); part = uni(part);
     const SkView w = sk_view(p, lds0);
     const float thr = p.sk_thr_f;
+    const double* S = w.xvals + capx;
     u32 n_cand = 0;
     SKT2(w.ctl, 0);
-    log_groups<BLOCK>(w.log_key + seg_base, w.log_val + seg_base, n, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
-        u32 cell[4];
+    log_groups<BLOCK>(w.log_key + seg_base, w.log_pu + seg_base, n, [&](const int (&k)[4], const u32 (&pu)[4], u32 g0) {
+        u32 cell[4]; double s[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cell[q] = w.U[((u32)max(k[q], 0) * kSkMulA) >> w.shU];    // four lookups in flight
+        for (int q = 0; q < 4; ++q) {                                                 // eight lookups in flight
+            cell[q] = w.U[((u32)max(k[q], 0) * kSkMulA) >> w.shU];
+            s[q] = S[k[q] >= 0 ? pu[q] - pu_base : 0u];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (g0 + 64u * (u32)q >= n) break;                                        // wave-uniform
             bool cand = k[q] >= 0;
-            if (use_u && cand) {
+            if (cand) {
                 const u32 dq = (u32)k[q] >> p.deg_shift;                              // min(deg, deg_sat); 0: dangling, always exact
                 cand = (float)cell[q] >= (float)dq * thr;                             // thr = rmax * 2^31 * (1 - 2^-10), rounded down
             }
@@ -241,16 +403,17 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
 
 // ---------------------------------------------------------------- SCAN
 // Drains the exact table (cap slots in use, C allocated; C % 4 == 0, slots in [cap, C) are empty): compact, cheap push test
-// on the packed degree, compact again, then indptr lookup / dangling rule / division / push list for the nodes that remain.
-// clear_u: the level sketch is dead (this is the level's last partition) -- zero it for the next level.
+// on the packed degree, compact again, then exact degree / dangling rule / division / push list for the nodes that remain.
+// clear_n > 0: the level sketch and the share table (clear_n values behind slot `cap`) are dead (this is the level's last
+// partition) -- zero them for the next level.  pu_next / cnext: the row's pusher number of the next list's entry 0, coef[level + 1].
 template <int BLOCK>
-__device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, u32 clear_u)
+__device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u32 nxt_sel, u32 clear_n, u32 pu_next, double cnext)
 {
     typedef int    i4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
     typedef u32    u4 __attribute__((ext_vector_type(4)));
     KP p = kparams();
-    lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); clear_u = uni(clear_u);
+    lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); clear_n = uni(clear_n); pu_next = uni(pu_next); cnext = uni(cnext);
     const SkView w = sk_view(p, lds0);
     CtlS* ctl = w.ctl;
     int* lkeys = w.xkeys; double* lvals = w.xvals;
@@ -260,9 +423,10 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
     u32* bt_g = w.bt2 + (size_t)nxt_sel * p.bt_cap;
     const int tid = threadIdx.x, lane = tid & 63;
     SKT2(ctl, 4);
-    if (clear_u) {
+    if (clear_n) {
         const u4 z = {0u, 0u, 0u, 0u};
         for (u32 i = 4u * (u32)tid; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
+        for (u32 i = (u32)tid; i < clear_n; i += BLOCK) lvals[cap + i] = 0.0;
     }
     constexpr u32 kWaves = BLOCK / 64;
     const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
@@ -271,7 +435,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
     for (u32 sub = wb; sub < wb + range && sub < cap; sub += 256u) {
         const u32 s0 = sub + 4u * (u32)lane;
         i4 kk = {kEmpty, kEmpty, kEmpty, kEmpty};
-        if (s0 < C) kk = *(const i4*)&lkeys[s0];
+        if (s0 < cap) kk = *(const i4*)&lkeys[s0];                  // (cap % 4 == 0)
         const bool o0 = kk.x != kEmpty, o1 = kk.y != kEmpty, o2 = kk.z != kEmpty, o3 = kk.w != kEmpty;
         const u64 m0 = __ballot(o0), m1 = __ballot(o1), m2 = __ballot(o2), m3 = __ballot(o3);
         const u32 c0 = (u32)__popcll(m0), c1 = (u32)__popcll(m1), c2 = (u32)__popcll(m2), c3 = (u32)__popcll(m3);
@@ -291,6 +455,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         tot += c0 + c1 + c2 + c3;
     }
+    (void)C;
     u32 st_push = 0, st_edges = 0, st_deg = 0;
     SKT2(ctl, 5);
     if (tot != 0) {
@@ -319,36 +484,28 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         SKT2(ctl, 6);
-        for (u32 j = 0; j < ncand; j += 128u) {
-            int k[2]; double r[2]; bool want[2]; int ds[2], de[2];
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const u32 idx = j + 64u * (u32)v + (u32)lane;
-                want[v] = idx < ncand; k[v] = kEmpty; r[v] = 0.0; ds[v] = 0; de[v] = 0;
-                if (want[v]) {
-                    k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
-                    lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
-                    const int node = (int)((u32)k[v] & p.node_mask);
-                    ds[v] = p.indptr[node]; de[v] = p.indptr[node + 1]; ++st_deg;           // graph.h:43-45
+        for (u32 j = 0; j < ncand; j += 64u) {
+            const u32 idx = j + (u32)lane;
+            const bool want = idx < ncand;
+            int k = kEmpty; double r = 0.0; u32 deg = 0;
+            if (want) {
+                k = lkeys[wb + idx]; r = lvals[wb + idx];
+                lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
+                deg = (u32)k >> p.deg_shift;
+                if (deg == p.deg_sat) { deg = sk_degree(p, (u32)k); ++st_deg; }           // graph.h:43-45 (a saturated degree field: one word of unit_info)
+            }
+            double share = 0.0; u32 len = 0;
+            if (want) {
+                if (deg == 0) {                                                       // graph.h:91-93
+                    __hip_atomic_fetch_add(&nx->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (r >= p.rmax * (double)deg) {                               // graph.h:94
+                    ++st_push; st_edges += deg;
+                    const double sh = r / (double)deg;                                // graph.h:95
+                    if (sh != 0.0) { share = sh; len = deg; }
                 }
             }
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                if (__ballot(want[v]) == 0) continue;                                     // wave-uniform
-                double share = 0.0; u32 len = 0;
-                if (want[v]) {
-                    const u32 deg = (u32)(de[v] - ds[v]);
-                    if (deg == 0) {                                                       // graph.h:91-93
-                        __hip_atomic_fetch_add(&nx->dangling, r[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else if (r[v] >= p.rmax * (double)deg) {                            // graph.h:94
-                        ++st_push; st_edges += deg;
-                        const double sh = r[v] / (double)deg;                             // graph.h:95
-                        if (sh != 0.0) { share = sh; len = deg; }
-                    }
-                }
-                push_alloc(p, ctl, nx, push, bt_g, len, (u32)ds[v], share, lane, w.bt_l, w.bt_l_cap);
-            }
+            sk_push_alloc(p, ctl, nx, push, bt_g, w.arch, pu_next, cnext, len, ((u32)k & p.node_mask) << kSkUnitShift, share, lane, w.bt_l, w.bt_l_cap);
         }
         SKT2(ctl, 7);
         st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
@@ -368,15 +525,16 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
 // its slot, so the claimed slots ARE the level's frontier and SCAN runs straight over that list, no table walk -- with
 // nothing but the wave's program order in between (LDS operations of one wave execute in order).  The other waves skip the
 // call and park at the one barrier behind it (the general path: two calls per wave, two barriers, a table walk).  An insert
-// that hits the probe limit (ctl->ovf) undoes the claims; the caller then walks the level's log like any overflowed level.
+// that hits the probe limit (ctl->ovf) undoes the claims; the caller then re-streams the level in hash partitions.
 constexpr u32 kSkSoloEdges = 256;
 template <int BLOCK>
 __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, double cs,
-                                                u32 has_dang, double dang, int seed_key, u32 nx_sel)
+                                                u32 has_dang, double dang, int seed_key, u32 nx_sel, u32 pu_base, u32 pu_next, double cnext)
 {
     KP p = kparams();
     lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs);
     has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); nx_sel = uni(nx_sel);
+    pu_base = uni(pu_base); pu_next = uni(pu_next); cnext = uni(cnext);
     const SkView w = sk_view(p, lds0);
     CtlS* ctl = w.ctl; int* lkeys = w.xkeys; double* lvals = w.xvals;
     const u32 lane = threadIdx.x & 63u;
@@ -389,8 +547,8 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
     const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
     PushEntry* push_nxt = w.push2 + (size_t)(cur ^ 1u) * p.push_cap;
     u32* bt_nxt = w.bt2 + (size_t)(cur ^ 1u) * p.bt_cap;
-    int* lk = w.log_key + seg_base; double* lv = w.log_val + seg_base;
-    // ---- the one step of the edge enumeration (as sk/edge_stream: entries flag their first edge, ballot, mbcnt, bpermute)
+    int* lk = w.log_key + seg_base; unsigned short* lp = w.log_pu + seg_base;
+    // ---- the one step of the edge enumeration (as sk_edge_stream: entries flag their first edge, ballot, mbcnt, bpermute)
     const PushEntry ent = push_cur[min(lane, n_ent - 1u)];
     const u32 off = lane < n_ent ? ent.off : 0xFFFFFFFFu;
     *(u32*)(wscr + 4 * lane) = 0u;
@@ -398,22 +556,21 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
     asm volatile("" ::: "memory");            // the word is written by OTHER lanes
     const u32 fl = *(const u32*)(wscr + 4 * lane);
     u32 before = (u32)__popcll(__ballot(off == 0u)) - 1u;
-    int col[4]; double sh[4];
+    int col[4]; double sh[4]; u32 own[4];
     {
-        u32 e[4];
+        const u64 sbits = (u64)__double_as_longlong(ent.share);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool mine = ((fl >> (8 * q)) & 1u) != 0;
             const u64 M = __ballot(mine);
-            e[q] = (before + lane_prefix(M) + (mine ? 1u : 0u)) << 2;
+            own[q] = before + lane_prefix(M) + (mine ? 1u : 0u);
             before += (u32)__popcll(M);
         }
-        const u64 sbits = (u64)__double_as_longlong(ent.share);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)ent.rel);
-            const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)sbits);
-            const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)e[q], (int)(u32)(sbits >> 32));
+            const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)(own[q] << 2), (int)ent.rel);
+            const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)(own[q] << 2), (int)(u32)sbits);
+            const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)(own[q] << 2), (int)(u32)(sbits >> 32));
             const u32 eq = 64u * (u32)q + lane;
             col[q] = p.indices[eq < E ? rel_e + eq : (u32)p.nnz];           // graph.h:97
             sh[q] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
@@ -427,7 +584,8 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
         const double vq = q < 4 ? sh[q] : dang;
         if (kq >= 0) {
             const u32 li = q < 4 ? 64u * (u32)q + lane : E;
-            __builtin_nontemporal_store(kq, &lk[li]); __builtin_nontemporal_store(vq, &lv[li]);      // graph.h:98 -> one log record per edge (next read by TOP-K)
+            __builtin_nontemporal_store(kq, &lk[li]);                                 // graph.h:98 -> one log record per edge (next read by TOP-K)
+            __builtin_nontemporal_store((unsigned short)(pu_base + (q < 4 ? own[q < 4 ? q : 0] : n_ent)), &lp[li]);
             if (cs != 0.0) lds_add_u32(&w.R[((u32)kq * kSkMulA) >> w.shR], fx_up(vq * cs));
         }
         u32 slot; int seen;
@@ -454,10 +612,10 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
         }
         const u32 dq = (u32)k >> p.deg_shift;
         const bool cand = valid && (dq == 0u || r >= p.rmax * (double)dq);
-        double share = 0.0; u32 len = 0, ds = 0;
+        double share = 0.0; u32 len = 0;
         if (cand) {
-            const int node = (int)((u32)k & p.node_mask);
-            ds = (u32)p.indptr[node]; const u32 deg = (u32)p.indptr[node + 1] - ds; ++st_deg;          // graph.h:43-45
+            u32 deg = dq;
+            if (dq == p.deg_sat) { deg = sk_degree(p, (u32)k); ++st_deg; }                            // graph.h:43-45
             if (deg == 0) {                                                                           // graph.h:91-93
                 __hip_atomic_fetch_add(&nx->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -467,7 +625,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
                 if (s_ != 0.0) { share = s_; len = deg; }
             }
         }
-        push_alloc(p, ctl, nx, push_nxt, bt_nxt, len, ds, share, (int)lane, w.bt_l, w.bt_l_cap);
+        sk_push_alloc(p, ctl, nx, push_nxt, bt_nxt, w.arch, pu_next, cnext, len, ((u32)k & p.node_mask) << kSkUnitShift, share, (int)lane, w.bt_l, w.bt_l_cap);
     }
     st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
     if (lane == 0) {
@@ -479,40 +637,27 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
 
 // ---------------------------------------------------------------- TOP-K
 struct SkTop {                             // TOP-K's carving of the LDS behind the control block
-    u32* R; u32 MR, shR; double* avals; int* akeys; u32 CA; Cand* tie; Cand* sel; u32* fine;
+    u32* R; u32 MR, shR; double* T; double* avals; int* akeys; u32 CA; Cand* tie; Cand* sel; u32* fine;
 };
-__device__ __forceinline__ SkTop sk_top(KP p, const SkView& w) {
+// bytes of the region TOP-K carves / slots of the aggregation table that remain beside T for n_pu pushers (0: T does not fit)
+__device__ __forceinline__ u32 sk_top_slots(u32 region_bytes, u32 n_pu, u32 K) {
+    const u32 fixed = 8u * ((n_pu + 1u) & ~1u) + 16u * (kSkTie + K);
+    return region_bytes > fixed ? ((region_bytes - fixed) / 12u) & ~3u : 0u;
+}
+__device__ __forceinline__ SkTop sk_top(KP p, const SkView& w, u32 n_pu) {
     SkTop t;
     t.MR = w.MR; t.shR = w.shR;
     t.R = w.R;
     const u32 region_bytes = 4u * w.MU + 12u * w.CX;
-    t.CA = ((region_bytes - 16u * (kSkTie + (u32)p.K)) / 12u) & ~3u;
-    const u32 a0 = w.lds_u;
+    t.CA = sk_top_slots(region_bytes, n_pu, (u32)p.K);
+    t.T = lds_at<double>(w.lds_u);
+    const u32 a0 = w.lds_u + 8u * ((n_pu + 1u) & ~1u);                                // (16-byte aligned)
     t.avals = lds_at<double>(a0);
     t.akeys = lds_at<int>(a0 + 8u * t.CA);
     t.tie = lds_at<Cand>(a0 + 12u * t.CA);
     t.sel = t.tie + kSkTie;
     t.fine = (u32*)((unsigned char*)w.ctl + kCtlStruct);                              // 1 024 words of flag bytes, idle in TOP-K
     return t;
-}
-// coef[level] of the records of one 64-lane window starting at record ws.  The level boundaries live in registers: lane l of
-// the wave holds seg_hi = seg_off[l + 1] (lanes >= n_levels: 0xFFFFFFFF) and cf = coef[l], so the window's level is a ballot
-// and its coefficient a readlane -- no LDS round trip.  Windows that straddle a boundary (the first levels hold a handful of
-// records) step through the levels they touch.
-__device__ __forceinline__ double sk_window_coef(u32 seg_hi, double cf, int n_levels, u32 ws, u32 lane)
-{
-    const u32 lo = (u32)(u64)__double_as_longlong(cf), hi = (u32)((u64)__double_as_longlong(cf) >> 32);
-    int l = (int)__popcll(__ballot(seg_hi <= ws));                                    // levels that end at or before ws
-    if (l >= n_levels) l = n_levels - 1;
-    u32 clo = (u32)__builtin_amdgcn_readlane((int)lo, l), chi = (u32)__builtin_amdgcn_readlane((int)hi, l);
-    const u32 idx = ws + lane;
-    while (l + 1 < n_levels && ws + 64u > (u32)__builtin_amdgcn_readlane((int)seg_hi, l)) {   // wave-uniform
-        const u32 edge = (u32)__builtin_amdgcn_readlane((int)seg_hi, l);
-        ++l;
-        const u32 nlo = (u32)__builtin_amdgcn_readlane((int)lo, l), nhi = (u32)__builtin_amdgcn_readlane((int)hi, l);
-        if (idx >= edge) { clo = nlo; chi = nhi; }
-    }
-    return __longlong_as_double((long long)(((u64)chi << 32) | clo));
 }
 
 // Select the K largest (value desc, column asc) positive totals of the aggregation table into sel[0 .. need) (graph.h:111-121),
@@ -649,20 +794,24 @@ __device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& m
     return need;
 }
 
-template <int BLOCK>
-__device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi, int seed, int n_levels, u32 n_log)
+// TG: coef * share of the row's pushers does not fit LDS beside a useful aggregation table (a hub's thousands of leaves all pushed):
+// the sweep gathers it from HBM instead (L2-hot: 8 bytes per pusher, re-read once per record).
+template <int BLOCK, bool TG>
+__device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi, int seed, u32 n_pu, u32 n_log)
 {
     KP p = kparams();
-    lds0 = uni(lds0); row_lo = uni(row_lo); row_hi = uni(row_hi); seed = uni(seed); n_levels = uni(n_levels); n_log = uni(n_log);
+    lds0 = uni(lds0); row_lo = uni(row_lo); row_hi = uni(row_hi); seed = uni(seed); n_pu = uni(n_pu); n_log = uni(n_log);
     const SkView w = sk_view(p, lds0);
     CtlS* ctl = w.ctl;
-    const SkTop t = sk_top(p, w);
+    const SkTop t = sk_top(p, w, TG ? 0u : n_pu);
     const long long row = (long long)(((u64)row_hi << 32) | row_lo);
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 wave = wave_id();
     const u32 K = (u32)p.K;
-    typedef u32 u4 __attribute__((ext_vector_type(4)));
 
+    // T = coef[level] * share of every pusher of the row (graph.h:90 / :109 per edge: what a record adds to its target's reserve).
+    // SCAN left them in HBM with the push-list entries; the level tables are dead and wiped by whoever used them last.
+    if (!TG) for (u32 i = tid; i < n_pu; i += BLOCK) t.T[i] = w.arch[i];
     for (u32 i = tid; i < 512u; i += BLOCK) t.fine[i] = 0;
     if (tid == 0) { ctl->ovf = 0; ctl->tk_t = 1u; }
     GP_SYNC();
@@ -698,9 +847,6 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
     SKT(ctl, 7);
     u32 t_c = uni(ctl->tk_t);
     u32 need = 0, my_rank = 0;
-    // level boundaries and coefficients of the log, lane-indexed (sk_window_coef)
-    const u32 seg_hi = lane < n_levels ? ctl->seg_off[lane + 1] : 0xFFFFFFFFu;
-    const double cf = lane < n_levels ? ctl->coef[lane] : 0.0;
     bool last = false;                                                                // t_c is a proven bound: what this round selects is final
     for (int round = 0; ; ++round) {
         // One round = every node whose cell reaches t_c, tabled exactly and the K best selected; in P hash partitions when
@@ -718,17 +864,18 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
                 GP_SYNC();
                 if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
-                log_groups<BLOCK, true>(w.log_key, w.log_val, n_log, [&](const int (&k)[4], const double (&s)[4], u32 g0) {
-                    u32 cell[4];
+                log_groups<BLOCK, true>(w.log_key, w.log_pu, n_log, [&](const int (&k)[4], const u32 (&pu)[4], u32 g0) {
+                    u32 cell[4]; double cv[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cell[q] = t.R[((u32)max(k[q], 0) * kSkMulA) >> t.shR];      // four lookups in flight
+                    for (int q = 0; q < 4; ++q) {                                     // eight lookups in flight
+                        cell[q] = t.R[((u32)max(k[q], 0) * kSkMulA) >> t.shR];
+                        cv[q] = TG ? w.arch[pu[q]] : t.T[pu[q]];
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const u32 ws = g0 + 64u * (u32)q;
-                        if (ws >= n_log) break;                                       // wave-uniform
-                        const double c = sk_window_coef(seg_hi, cf, n_levels, ws, (u32)lane);
-                        const bool hit = k[q] >= 0 && c != 0.0 && cell[q] >= t_c;
-                        insert_window_asm(t.akeys, t.avals, t.CA, &ctl->ovf, hit ? k[q] : -1, c * s[q], P, part);   // graph.h:90 / :109
+                        if (g0 + 64u * (u32)q >= n_log) break;                        // wave-uniform
+                        const bool hit = k[q] >= 0 && cv[q] != 0.0 && cell[q] >= t_c;
+                        insert_window_asm(t.akeys, t.avals, t.CA, &ctl->ovf, hit ? k[q] : -1, cv[q], P, part);   // graph.h:90 / :109
                     }
                 });
                 GP_SYNC();
@@ -758,12 +905,13 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
         }
         if (tid == 0) zstat(ctl, zSweep2, 1);
     }
-    // write the row in output order (value desc, column asc)
+    // write the row in output order (value desc, column asc): keys are unit numbers, which grow with the node ids they stand for
     const long long out0 = row * (long long)p.K;
     if ((u32)tid < need) {
         const Cand cd = t.sel[tid];
+        const int node = p.unit_info[(u32)cd.key & p.node_mask];
         __builtin_nontemporal_store(seed, &p.out_row[out0 + my_rank]);                                          // graph.h:122
-        __builtin_nontemporal_store((int)((u32)cd.key & p.node_mask), &p.out_col[out0 + my_rank]);             // graph.h:123
+        __builtin_nontemporal_store(node, &p.out_col[out0 + my_rank]);                                          // graph.h:123
         __builtin_nontemporal_store(__longlong_as_double((long long)cd.bits), &p.out_val[out0 + my_rank]);     // graph.h:124
     }
     publish_filled(p, row, need);
@@ -779,8 +927,8 @@ __device__ __forceinline__ void sk_wipe(const SkView& w) {
     for (u32 i = threadIdx.x; i < w.CX; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
 }
 template <int BLOCK>
-__device__ __forceinline__ void sk_wipe_x(const SkView& w) {
-    for (u32 i = threadIdx.x; i < w.CX; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
+__device__ __forceinline__ void sk_wipe_x(const SkView& w, u32 capx) {
+    for (u32 i = threadIdx.x; i < capx; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
 }
 
 template <int BLOCK>
@@ -809,6 +957,8 @@ __device__ __forceinline__ void gfpush_sk_rows()
     // (a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
     //  hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax)
     const double solo_e_bound = p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz;
+    const u32 pu_cap = (u32)min((u64)kSkMaxPushers, p.arch_cap);                      // pusher numbers the row may hand out
+    const u32 top_region = 4u * w.MU + 12u * CX;
 
     for (;;) {
         GP_SYNC();
@@ -825,22 +975,25 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (tid == 0) { __hip_atomic_fetch_add(&ctl->st[zFailed], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p.out_filled) p.out_filled[row] = 0; }
             continue;
         }
-        const u32 s_start = uni((u32)p.indptr[seed]);
-        const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - s_start;
-        const int seed_key = (int)((u32)seed | (min(seed_deg, p.deg_sat) << p.deg_shift));
+        const u32 seed_unit = uni(p.node_pos[seed]);
+        const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - uni((u32)p.indptr[seed]);
+        const u32 s_start = seed_unit << kSkUnitShift;
+        const int seed_key = (int)(seed_unit | (min(seed_deg, p.deg_sat) << p.deg_shift));
 
         u32 n_ent_cur = 0, e_cur = 0, log_pos = 1;
         double dang_cur = 0.0; bool has_dang_cur = false;
-        int cur = 1, n_levels = 1;
+        int cur = 1;
+        u32 pu_cur = 1;                                 // pusher number of the current list's entry 0 (number 0: the seed's own record)
         // ---- level 0: the frontier is { seed : 1.0 } (graph.h:81): its record, push test and push-list entry directly
         {
             PushEntry* push1 = w.push2 + (size_t)1 * p.push_cap;
             u32* bt1 = w.bt2 + (size_t)1 * p.bt_cap;
             if (tid == 0) {
-                if (p.log_cap > 0) { w.log_key[0] = seed_key; w.log_val[0] = 1.0; } else ctl->fail = 1;   // graph.h:90
+                if (p.log_cap > 0 && pu_cap >= 2u) {                                               // graph.h:90
+                    w.log_key[0] = seed_key; w.log_pu[0] = 0; w.arch[0] = ctl->coef[0];
+                } else ctl->fail = 1;
                 lds_add_u32(&w.R[((u32)seed_key * kSkMulA) >> w.shR], fx_up(ctl->coef[0] * p.sk_rscale));
-                ctl->seg_off[0] = 0;
-                zstat(ctl, zDeg, 1); zstat(ctl, zLevels, 1);
+                zstat(ctl, zLevels, 1);
             }
             if (L > 0) {
                 if (seed_deg == 0) { dang_cur = 1.0; has_dang_cur = true; }           // graph.h:91-93
@@ -850,7 +1003,10 @@ __device__ __forceinline__ void gfpush_sk_rows()
                     if (share != 0.0) {
                         e_cur = seed_deg; n_ent_cur = 1;
                         if (tid == 0) {
-                            if (p.push_cap > 0) { PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push1[0] = pe; } else ctl->fail = 1;
+                            if (p.push_cap > 0 && pu_cap >= 2u) {
+                                PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push1[0] = pe;
+                                w.arch[1] = ctl->coef[1] * share;
+                            } else ctl->fail = 1;
                         }
                         const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
                         if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
@@ -866,25 +1022,32 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (n_rec == 0 || uni(ctl->fail)) break;                                  // the frontier died: later levels add nothing
             const bool last = lvl == L;                                               // graph.h:104-110: no push from the last level
             max_e = max(max_e, e_cur);
-            if ((u64)log_pos + n_rec > p.log_cap) { if (tid == 0) ctl->fail = 1; GP_SYNC(); break; }      // (fail = 1: a slab bound, counted for the host's slab sizing; 3: anything else)
+            // (fail = 1: a slab bound, counted for the host's slab sizing; anything else has its own number)
+            if ((u64)log_pos + n_rec > p.log_cap || (u64)pu_cur + n_ent_cur + 1u > pu_cap) { if (tid == 0) ctl->fail = 1; GP_SYNC(); break; }
             const u32 seg_base = log_pos;
+            const u32 pu_next = pu_cur + n_ent_cur + (has_dang_cur ? 1u : 0u);        // ... of the NEXT list's entry 0
             LevelCtr* nx = &ctl->lc[lvl & 1];
             if (tid == 0) {
                 nx->dangling = 0.0; nx->n_dangling = 0; nx->n_rec = 0; nx->alloc = 0ull;
-                ctl->seg_off[lvl] = seg_base;
+                if (has_dang_cur) w.arch[pu_cur + n_ent_cur] = ctl->coef[lvl] * dang_cur;         // graph.h:92: the record of the mass returned to the seed
                 zstat(ctl, zLevels, 1);
             }
-            n_levels = lvl + 1;
             log_pos += n_rec;
             const double cs = uni(ctl->coef[lvl]) * p.sk_rscale;                      // reserve-sketch units per unit of share
+            const double cnext = last ? 0.0 : uni(ctl->coef[lvl + 1]);
             SKT(ctl, 6);
             if (last) {
-                phase_sk_stream<BLOCK, 2>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, 0u, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+                phase_sk_stream<BLOCK, 2>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, 0u, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, 1u, 0u);
                 SKT(ctl, 3);
+                pu_cur = pu_next;
                 break;
             }
-            const bool direct = n_rec <= direct_max;
-            u32 capx = direct ? min(CX, max(kMinCap, (4u * n_rec + 3u) & ~3u)) : CX;
+            // a sketch level keeps its share table (one value per pusher, one for the dangling mass) behind the slots it uses; a level
+            // with more pushers than that leaves room for (a hub's thousands of leaves all push) goes without the sketch, whatever its size
+            const u32 s_n = n_ent_cur + 1u;
+            const bool direct = n_rec <= direct_max || s_n + kMinCap > CX;
+            u32 capx = direct ? min(CX, max(kMinCap, (4u * n_rec + 3u) & ~3u)) : (CX - s_n) & ~3u;
+            const u32 cap0 = capx;                                                    // (where the share table starts)
             // Partitions planned so that the nodes expected in the exact table -- per pushed edge what this workgroup's earlier
             // rows tabled at this level, x 1.25 -- fit its slots: an overflowed pass costs a whole pass, a planned partition one
             // too (measured, planning for a load of 0.5 / 0.6 / 0.7 / 0.8 / 1.0 / 1.2: 24.75 / 24.2 / 23.95 / 23.75 / 23.54 / 23.57 ms)
@@ -892,39 +1055,43 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (!direct) {
                 const u32 q = uni(ctl->cand_q[lvl]);
                 const u32 est = (u32)(((u64)n_rec * q) >> 10);
-                if (q != 0 && est > CX) P0 = min(64u, (est + CX - 1u) / CX);
-            }
+                if (q != 0 && est > capx) P0 = min(64u, (est + capx - 1u) / capx);
+            } else if (n_rec > direct_max) P0 = min(64u, (n_rec + CX / 2u - 1u) / (CX / 2u));        // (every edge is an insert: half a table per partition)
             // a small level: one wave does it, the others park at one barrier (phase_sk_solo)
-            const bool solo = p.solo && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&
-                              p.push_cap >= (u64)kSkSoloEdges + 4u && (double)p.bt_cap >= solo_e_bound / (double)(1u << kUnitShift) + 4.0;
+            const bool solo = p.solo && direct && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&
+                              p.push_cap >= (u64)kSkSoloEdges + 4u && (u64)pu_next + kSkSoloEdges + 4u <= pu_cap &&
+                              (double)p.bt_cap >= solo_e_bound / (double)(1u << kUnitShift) + 4.0;
             if (solo) {
                 if (wave_id() == 0)
-                    phase_sk_solo<BLOCK>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, has_dang_cur ? 1u : 0u, dang_cur, seed_key, (u32)(lvl & 1));
+                    phase_sk_solo<BLOCK>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, has_dang_cur ? 1u : 0u, dang_cur, seed_key, (u32)(lvl & 1), pu_cur, pu_next, cnext);
                 GP_SYNC();
                 SKT(ctl, 1); SKT_COUNT(ctl, 13, 1);
             } else {
             SKT2_BEGIN(ctl);
-            if (direct) phase_sk_stream<BLOCK, 1>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
-            else        phase_sk_stream<BLOCK, 0>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key);
+            if (direct) phase_sk_stream<BLOCK, 1>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, P0, 0u);
+            else        phase_sk_stream<BLOCK, 0>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, 1u, 0u);
             SKT2(ctl, 11);
             GP_SYNC();
             SKT2(ctl, 12);
             SKT(ctl, direct ? 1 : 2); SKT_COUNT(ctl, direct ? 13 : 14, 1);
             }
             // Exact inserts, then SCAN.  A table that overflows is wiped and the level's candidates are walked in hash
-            // partitions (q of P, split in two in place), exactly as the general kernel refines its partitions.
+            // partitions (q of P, split in two in place), exactly as the general kernel refines its partitions: a sketch level
+            // re-reads its log segment, a small level re-streams its edges.
+            const bool by_log = !direct;
             bool u_dirty = !direct, first = true;
             u32 part = 0, np = P0;
             bool level_done = false;
             if (solo) {
                 if (!uni(ctl->ovf)) level_done = true;                                // (the wave wrote the next push list and lc[lvl & 1] itself)
-                else { capx = CX; }                                                   // undone: walk the level's log (first pass below sees ctl->ovf)
+                else { capx = CX; }                                                   // undone: re-stream the level (first pass below sees ctl->ovf)
             }
             if (!level_done)
             for (;;) {
                 if (!(first && direct)) {
                     SKT2_BEGIN(ctl);
-                    phase_sk_filter<BLOCK>(lds0, seg_base, n_rec, capx, direct ? 0u : 1u, np, part);
+                    if (by_log) phase_sk_filter<BLOCK>(lds0, seg_base, n_rec, capx, pu_cur, np, part);
+                    else        phase_sk_stream<BLOCK, 3>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, np, part);
                     SKT2(ctl, 2);
                     GP_SYNC();
                     SKT2(ctl, 3);
@@ -932,10 +1099,10 @@ __device__ __forceinline__ void gfpush_sk_rows()
                 }
                 first = false;
                 if (uni(ctl->ovf)) {
-                    sk_wipe_x<BLOCK>(w);
+                    sk_wipe_x<BLOCK>(w, by_log ? cap0 : CX);                          // (a sketch level's share table lives behind slot cap0)
                     GP_SYNC();
                     if (tid == 0) ctl->ovf = 0;
-                    capx = CX;
+                    if (!by_log) capx = CX;
                     if (np < 0x10000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
                     if (tid == 0) ctl->fail = 5;                                      // (5: a level's candidates in > 65 536 partitions)
                     GP_SYNC();
@@ -943,7 +1110,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
                 }
                 const bool final_part = np == P0 && part + 1u == P0;                  // nothing reads the sketch after this partition
                 SKT2_BEGIN(ctl);
-                phase_sk_scan<BLOCK>(lds0, capx, (u32)(lvl & 1), (u32)(cur ^ 1), final_part && u_dirty ? 1u : 0u);
+                phase_sk_scan<BLOCK>(lds0, capx, (u32)(lvl & 1), (u32)(cur ^ 1), final_part && u_dirty ? s_n : 0u, pu_next, cnext);
                 if (final_part) u_dirty = false;
                 SKT2(ctl, 9);
                 GP_SYNC();
@@ -958,6 +1125,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
                 typedef u32 u4 __attribute__((ext_vector_type(4)));
                 const u4 z = {0u, 0u, 0u, 0u};
                 for (u32 i = 4u * (u32)tid; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
+                for (u32 i = (u32)tid; i < s_n; i += BLOCK) w.xvals[cap0 + i] = 0.0;
                 GP_SYNC();
             }
             if (uni(ctl->fail)) break;
@@ -969,13 +1137,17 @@ __device__ __forceinline__ void gfpush_sk_rows()
             { const u64 al = uni(nx->alloc); n_ent_cur = (u32)al; e_cur = (u32)(al >> 32); }
             has_dang_cur = uni(nx->n_dangling) != 0; dang_cur = has_dang_cur ? uni(nx->dangling) : 0.0;
             cur ^= 1;
+            pu_cur = pu_next;
         }
-        if (tid == 0) ctl->seg_off[n_levels] = log_pos;
         GP_SYNC();
         SKT(ctl, 6);
         max_log = max(max_log, log_pos);
-        if (!uni(ctl->fail))
-            phase_sk_topk<BLOCK>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, n_levels, log_pos);
+                if (!uni(ctl->fail)) {
+            // (T beside at least half of the aggregation table TOP-K has without it; else the gathering form)
+            if (2u * sk_top_slots(top_region, pu_cur, (u32)p.K) >= sk_top_slots(top_region, 0u, (u32)p.K))
+                 phase_sk_topk<BLOCK, false>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, pu_cur, log_pos);
+            else phase_sk_topk<BLOCK, true>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, pu_cur, log_pos);
+        }
         GP_SYNC();
         if (uni(ctl->fail)) {
             // the row leaves for the retry list (the general kernel recounts it); nothing of it was written
@@ -984,7 +1156,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
                 p.retry_list[i] = (u32)row;
                 if (ctl->fail == 1) __hip_atomic_fetch_add(&p.counters[kSkSlabFails], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifndef GP_SK_TIMING
-                __hip_atomic_fetch_add(&p.counters[kDiag0 + min(ctl->fail, 7u)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // why rows left (diag_sub[1..5])
+                __hip_atomic_fetch_add(&p.counters[kDiag0 + min(ctl->fail, 7u)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // why rows left (diag_sub[1..6])
 #endif
             }
             if (tid < 8) ctl->st_row[tid] = 0;

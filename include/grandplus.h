@@ -240,6 +240,16 @@ int gp_propagate_features(gp_graph* g, const float* d_features, int32_t feat_dim
  * above *node_mask; packs them first if that has not happened yet) */
 int gp_internal_graph_csr(gp_graph* g, const int** d_indptr, const int** d_indices, uint32_t* node_mask, void* stream);
 
+/* internal (tests): the SELF-ADDRESSED copy of the CSR the sketch kernel runs on (built now if it does not exist yet), copied
+ * to the host.  Rows start at units of 32 column words (128 bytes); node_pos[u] = first unit of row u (n_nodes + 1 entries); a
+ * column word is (unit of the target) | min(deg(target), *deg_sat) << *unit_bits; padding and the sentinel word
+ * acsr[32 * *n_units] are -1; unit_info[first unit of a row] = its node id, [second unit of a multi-unit row] = its degree.
+ * Call with NULL buffers for the sizes, then with h_acsr int32[32 * n_units + 1], h_node_pos uint32[n_nodes + 1], h_unit_info
+ * int32[n_units].  *n_units = 0: the graph does not allow the layout (unit numbers would leave fewer than two degree bits) and
+ * the general kernel takes every call. */
+int gp_internal_graph_acsr(gp_graph* g, int32_t* h_acsr, uint32_t* h_node_pos, int32_t* h_unit_info,
+                           int64_t* n_units, int* unit_bits, uint32_t* deg_sat);
+
 /* internal: the extended counters of the diagnostic build (-DGP_DIAG; all 0 in the product library): [0] wave
  * cycles, [1] cycles the waves waited at workgroup barriers, [2] barriers passed, [16 + 6*level + k] per level
  * (k = 0 expand ticks, 1 scan ticks, 2 edges, 3 frontier nodes, 4 push-list entries, 5 table passes); n <= 128 */

@@ -1,6 +1,6 @@
 """bench.py's multi-rank orchestration on CPU: `--gpus 2` rank code end to end under gloo -- sharding of every
 step's batch, the fixed warm-up, the fences, the gather, the max-over-ranks reductions, ONE JSON line on rank 0 -- with the
-compute swapped for the CPU oracle through bench.py's test seam (GRANDPLUS_BENCH_DEVICE=cpu + bench._GRAPH_FACTORY).  The product
+compute swapped for the CPU oracle: this test passes its own `platform` (Graph class, events, device) to bench.run_rank.  The product
 Graph class is not involved: this pins the launcher contract before an 8-GPU driver run meets it."""
 import json
 import os
@@ -50,17 +50,38 @@ class _OracleGraph:
         return dict(self._st)
 
 
+class _HostEvent:
+    """torch.cuda.Event stand-in (perf_counter stamps)."""
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self):
+        import time
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class _CpuPlatform:
+    """The stand-in for bench.CudaPlatform: CPU tensors, host clocks, the oracle-backed Graph above."""
+    name = "cpu test stand-in"
+    graph_class = staticmethod(lambda: _OracleGraph)
+    event = staticmethod(lambda: _HostEvent())
+    device = staticmethod(lambda local_rank: torch.device("cpu"))
+    sync = staticmethod(lambda dev: None)
+
+
 def _rank(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
-                      GRANDPLUS_BENCH_BACKEND="gloo", GRANDPLUS_BENCH_DEVICE="cpu")
+                      GRANDPLUS_BENCH_BACKEND="gloo")
     import bench
-    bench._GRAPH_FACTORY = _OracleGraph
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--prewarm", "2", "--workload", "pubmed",
                 "--seeds-per-gpu", "96", "--no-cpu-baseline", "--no-host-api", "--no-next-rows"]
     out = open(os.path.join(out_dir, f"rank{rank}.out"), "w")
     sys.stdout = out
-    rc = bench.run_rank(bench.parse_args())
+    rc = bench.run_rank(bench.parse_args(), platform=_CpuPlatform)
     out.flush()
     assert rc == 0
 
@@ -80,11 +101,13 @@ def test_bench_two_ranks_under_gloo_print_one_json_line(tmp_path):
     assert "roofline" in line and line["roofline"]["bound"] == "hbm" and line["vs_baseline"] is None
 
 
-def test_bench_cpu_seam_without_an_injected_graph_refuses(tmp_path, monkeypatch):
-    """The seam is not a CPU path: on its own it measures nothing."""
+def test_bench_has_no_cpu_path_of_its_own(monkeypatch):
+    """bench.py selects nothing but the product: with the default platform and no GPU the rank stops at GP_ERR_NO_DEVICE."""
+    import pytest
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the default platform would run the benchmark")
     sys.path.insert(0, ROOT)
     import bench
-    monkeypatch.setenv("GRANDPLUS_BENCH_DEVICE", "cpu")
-    monkeypatch.setattr(bench, "_GRAPH_FACTORY", None)
+    assert not hasattr(bench, "_GRAPH_FACTORY") and "GRANDPLUS_BENCH_DEVICE" not in open(bench.__file__).read()
     monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "pubmed", "--seeds-per-gpu", "8", "--steps", "1", "--warmup", "0"])
     assert bench.run_rank(bench.parse_args()) == 3

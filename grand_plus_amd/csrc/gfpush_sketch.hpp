@@ -73,6 +73,9 @@ struct CtlS {
     u64 st[8], st_row[8];                 // statistics: workgroup totals / the row in flight
     double coef[kSkMaxCoef];
     u32 cand_q[kSkMaxCoef];               // per level: exact-table nodes per pushed edge of this workgroup's earlier rows (x 1.25, in 1/1024)
+    int seed_key; u32 tot_pu, tot_log;    // the row in flight: its seed's key; pushers numbered and log records written so far
+    double lv_dang; u32 lv_has_dang;      // the level in flight: mass its dangling nodes return to the seed (thread 0 writes them at the top of the level and is their only reader: STREAM's tail)
+    u32 max_e, max_log;                   // largest level / log this workgroup has seen (statistics)
 #ifdef GP_SK_TIMING
     u64 tacc[16]; u64 tlast;              // -DGP_SK_TIMING: 100 MHz ticks thread 0 spent per phase (flushed to the diag_sub counters)
     u64 tacc2[14]; u64 tlast2;            // ... and inside FILTER / SCAN / STREAM (tools/sk_phases.py)
@@ -318,17 +321,63 @@ __device__ __forceinline__ void sk_push_alloc(KP p, CtlS* ctl, LevelCtr* nx, Pus
     }
 }
 
+// insert_window_asm of gfpush_kernels.hpp without the partition filter and with the hash constants as literals (six scalar
+// registers fewer: a small level's STREAM holds its whole enumeration state in scalars beside it, and one spilled scalar there is
+// a scratch round trip per call).
+__device__ __forceinline__ void insert_window_all_asm(int* keys, double* vals, u32 cap, u32* flag, int col, double sh)
+{
+    u32 t, h, slot, seen, st; u64 sv, ent;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_i32 vcc, -1, %[col]\n\t"                       // lanes that hold an edge
+        "s_cbranch_execz 5f\n\t"
+        "s_mov_b64 %[ent], exec\n\t"
+        "s_mov_b32 %[st], 0x9e3779b1\n\t"                         // hash_a -> home slot (its constants pass through the step counter's register)
+        "v_mul_lo_u32 %[h], %[col], %[st]\n\t"
+        "v_lshrrev_b32 %[t], 15, %[h]\n\t"
+        "v_xor_b32 %[h], %[t], %[h]\n\t"
+        "s_mov_b32 %[st], 0x85ebca77\n\t"
+        "v_mul_lo_u32 %[h], %[h], %[st]\n\t"
+        "v_mul_hi_u32 %[slot], %[h], %[capm]\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "1:\n\t"
+        "v_lshl_add_u32 %[t], %[slot], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[seen], %[t], %[emp], %[col]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmpx_ne_u32 vcc, %[seen], %[col]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[seen]\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[slot], %[st], %[slot]\n\t"
+        "s_add_u32 %[st], %[st], 1\n\t"
+        "s_cmp_le_u32 %[st], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "v_mov_b32 %[t], 1\n\t"                                   // probe limit reached: the lanes still searching give up
+        "v_mov_b32 %[h], %[fa]\n\t"
+        "ds_write_b32 %[h], %[t]\n"
+        "2:\n\t"
+        "s_andn2_b64 exec, %[ent], exec\n\t"                      // the lanes that found or claimed their slot
+        "v_lshl_add_u32 %[t], %[slot], 3, %[vb]\n\t"
+        "ds_add_f64 %[t], %[sh]\n"
+        "5:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t] "=&v"(t), [h] "=&v"(h), [slot] "=&v"(slot), [seen] "=&v"(seen), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
+        : [col] "v"(col), [sh] "v"(sh), [emp] "v"(kEmpty),
+          [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
+}
+
 // ---------------------------------------------------------------- STREAM
 // MODE 0: log + reserve sketch + level sketch U + share table.   MODE 1: log + reserve sketch + exact insert into X (small levels).
-// MODE 2: log + reserve sketch (last level).   MODE 3: exact inserts of hash partition `part` of `parts` only (a small level whose
-// table overflowed: its records and sketch adds exist).   cs = coef[level] * scale: reserve-sketch units per unit of share.
+// MODE 2: log + reserve sketch (last level; the first pass of a level without the sketch that is walked in partitions from the start).
+// MODE 3: exact inserts of hash partition `part` of `parts` only (a small level whose table overflowed, or that is walked in partitions:
+// its records and sketch adds exist).   cs = coef[level] * scale: reserve-sketch units per unit of share.
 template <int BLOCK, int MODE>
 __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, double cs, u32 capx,
-                                                  u32 has_dang, double dang, int seed_key, u32 pu_base, u32 parts, u32 part)
+                                                  u32 pu_base, u32 parts, u32 part)
 {
     KP p = kparams();
     lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs); capx = uni(capx);
-    has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); pu_base = uni(pu_base); parts = uni(parts); part = uni(part);
+    pu_base = uni(pu_base); parts = uni(parts); part = uni(part);
     const SkView w = sk_view(p, lds0);
     const u32 lane = threadIdx.x & 63u;
     int* lk = w.log_key + seg_base; unsigned short* lp = w.log_pu + seg_base;
@@ -350,17 +399,19 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
                 if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(sh[q] * cs));       // graph.h:90 / :109, as an upper bound
                 if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(sh[q] * 2147483648.0));
             }
-            if (MODE == 1 || MODE == 3) insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q], parts, part);
+            if (MODE == 1) insert_window_all_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q]);
+            if (MODE == 3) insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q], parts, part);
         }
     });
-    if (threadIdx.x == 0 && has_dang) {                                               // graph.h:92: the seed gets the dangling mass
+    if (threadIdx.x == 0 && w.ctl->lv_has_dang) {                                     // graph.h:92: the seed gets the dangling mass
+        const double dang = w.ctl->lv_dang; const int seed_key = w.ctl->seed_key;
         if (MODE != 3) {
             lk[E] = seed_key; lp[E] = (unsigned short)(pu_base + n_ent);
             const u32 h = (u32)seed_key * kSkMulA;
             if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(dang * cs));
             if (MODE == 0) { lds_add_u32(&w.U[h >> w.shU], fx_up(dang * 2147483648.0)); S[n_ent] = dang; }
         }
-        if ((MODE == 1 || MODE == 3) && (parts == 1u || slot_of(hash_b((u32)seed_key), parts) == part) &&
+        if ((MODE == 1 || (MODE == 3 && (parts == 1u || slot_of(hash_b((u32)seed_key), parts) == part))) &&
             !res_add_lds(w.xkeys, w.xvals, capx, seed_key, dang)) w.ctl->ovf = 1;
     }
 }
@@ -375,6 +426,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
     lds0 = uni(lds0); seg_base = uni(seg_base); n = uni(n); capx = uni(capx); pu_base = uni(pu_base); parts = uni(parts); part = uni(part);
     const SkView w = sk_view(p, lds0);
     const float thr = p.sk_thr_f;
+    const u32 dshift = (u32)p.deg_shift;                                              // (a kernel-argument read inside the loop is re-issued behind every asm block)
     const double* S = w.xvals + capx;
     u32 n_cand = 0;
     SKT2(w.ctl, 0);
@@ -390,7 +442,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
             if (g0 + 64u * (u32)q >= n) break;                                        // wave-uniform
             bool cand = k[q] >= 0;
             if (cand) {
-                const u32 dq = (u32)k[q] >> p.deg_shift;                              // min(deg, deg_sat); 0: dangling, always exact
+                const u32 dq = (u32)k[q] >> dshift;                                   // min(deg, deg_sat); 0: dangling, always exact
                 cand = (float)cell[q] >= (float)dq * thr;                             // thr = rmax * 2^31 * (1 - 2^-10), rounded down
             }
             n_cand += (u32)__popcll(__ballot(cand));
@@ -919,16 +971,223 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
 }
 
 // ---------------------------------------------------------------- the row loop
+// (The row loop itself holds nothing per thread: whatever needs threadIdx-derived addresses is a function of its own.  Hoisted into
+//  the loop those values live across every phase call, the 24 callee-saved registers of an 80-VGPR budget do not hold them, and
+//  every reload from scratch is a memory round trip on the row's critical path -- 18 scratch operations per level measured +8 %.)
+// what: 1 = R, U and the whole exact table (row end), 2 = the first n slots of the exact table (an overflowed pass),
+//       3 = U and n share-table values behind slot `at` (a split partition walk of a sketch level)
 template <int BLOCK>
-__device__ __forceinline__ void sk_wipe(const SkView& w) {
+__device__ GP_PHASE_NOINLINE void phase_sk_wipe(u32 lds0, u32 what, u32 n, u32 at)
+{
     typedef u32 u4 __attribute__((ext_vector_type(4)));
+    KP p = kparams();
+    lds0 = uni(lds0); what = uni(what); n = uni(n); at = uni(at);
+    const SkView w = sk_view(p, lds0);
     const u4 z = {0u, 0u, 0u, 0u};
-    for (u32 i = 4u * threadIdx.x; i < w.MR + w.MU; i += 4u * BLOCK) *(u4*)&w.R[i] = z;     // R and U are adjacent
-    for (u32 i = threadIdx.x; i < w.CX; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
+    if (what == 1u) {
+        for (u32 i = 4u * threadIdx.x; i < w.MR + w.MU; i += 4u * BLOCK) *(u4*)&w.R[i] = z;     // R and U are adjacent
+        n = w.CX;
+    }
+    if (what == 3u) {
+        for (u32 i = 4u * threadIdx.x; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
+        for (u32 i = threadIdx.x; i < n; i += BLOCK) w.xvals[at + i] = 0.0;
+        return;
+    }
+    for (u32 i = threadIdx.x; i < n; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
 }
+
+// What a level hands to the next one sits in LDS, not in registers of the row loop: SCAN's counters in lc[level & 1] (push list
+// entries and edges, dangling mass) and, in that struct's spare word, the row's running pusher number and log position, which
+// thread 0 writes at the top of the level (like the counters' reset: the parity scheme keeps a slow wave's reads of the other set
+// apart).  Every wave derives the level's plan from those with scalar code; the row loop carries nothing but the level number.
+__device__ __forceinline__ u64 sk_io_pack(u32 pu_next, u32 log_next) { return ((u64)log_next << 32) | pu_next; }
+
+// Level 0 of a row: the frontier is { seed : 1.0 } (graph.h:81): its record, push test and push-list entry directly; what it
+// leaves for level 1 goes where every level leaves it: lc[0].
 template <int BLOCK>
-__device__ __forceinline__ void sk_wipe_x(const SkView& w, u32 capx) {
-    for (u32 i = threadIdx.x; i < capx; i += BLOCK) { w.xkeys[i] = kEmpty; w.xvals[i] = 0.0; }
+__device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); seed = uni(seed);
+    const SkView w = sk_view(p, lds0);
+    CtlS* ctl = w.ctl;
+    const int tid = threadIdx.x;
+    const u32 L = (u32)p.n_coef - 1u;
+    const u32 seed_unit = uni(p.node_pos[seed]);
+    const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - uni((u32)p.indptr[seed]);
+    const u32 s_start = seed_unit << kSkUnitShift;
+    const int seed_key = (int)(seed_unit | (min(seed_deg, p.deg_sat) << p.deg_shift));
+    const u32 pu_cap = (u32)min((u64)kSkMaxPushers, p.arch_cap);
+    PushEntry* push1 = w.push2 + (size_t)1 * p.push_cap;
+    u32* bt1 = w.bt2 + (size_t)1 * p.bt_cap;
+    const bool room = p.log_cap > 0 && pu_cap >= 2u && p.push_cap > 0;
+    bool pushes = false; double share = 0.0;
+    if (L > 0 && seed_deg != 0 && 1.0 >= p.rmax * (double)seed_deg) {                // graph.h:94
+        share = 1.0 / (double)seed_deg;                                               // graph.h:95
+        pushes = share != 0.0;
+        if (tid == 0) { zstat(ctl, zPush, 1); zstat(ctl, zEdges, seed_deg); }
+    }
+    const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
+    if (tid == 0) {
+        ctl->seed_key = seed_key; ctl->tot_pu = 1; ctl->tot_log = 1;
+        if (room) { w.log_key[0] = seed_key; w.log_pu[0] = 0; w.arch[0] = ctl->coef[0]; }      // graph.h:90
+        if (!room || (pushes && (u64)units > p.bt_cap)) ctl->fail = 1;
+        lds_add_u32(&w.R[((u32)seed_key * kSkMulA) >> w.shR], fx_up(ctl->coef[0] * p.sk_rscale));
+        zstat(ctl, zLevels, 1);
+        LevelCtr* l0 = &ctl->lc[0];
+        l0->dangling = L > 0 && seed_deg == 0 ? 1.0 : 0.0; l0->n_dangling = L > 0 && seed_deg == 0 ? 1u : 0u;   // graph.h:91-93
+        l0->n_rec = 0; l0->alloc = pushes ? ((u64)seed_deg << 32) | 1ull : 0ull; l0->pad1 = sk_io_pack(1u, 1u);
+        if (pushes && room) {
+            PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push1[0] = pe;
+            w.arch[1] = ctl->coef[1] * share;
+        }
+    }
+    if (pushes && (u64)units <= p.bt_cap)
+        for (u32 m = (u32)tid; m < units; m += BLOCK) { bt1[m] = 0u; if (m < w.bt_l_cap) w.bt_l[m] = 0u; }
+}
+
+// One level l = 1..L of a row (graph.h:83-110).  Returns 0 when the row's levels are done (last level, dead frontier, or the row
+// leaves: ctl->fail), 1 to go on.  Every path out has passed the level's last barrier or has touched nothing shared.
+template <int BLOCK>
+__device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl)
+{
+    KP p = kparams();
+    lds0 = uni(lds0); lvl = uni(lvl);
+    const SkView w = sk_view(p, lds0);
+    CtlS* ctl = w.ctl;
+    const int tid = threadIdx.x;
+    const u32 CX = w.CX;
+    const u32 L = (u32)p.n_coef - 1u;
+    const LevelCtr* in = &ctl->lc[(lvl & 1u) ^ 1u];
+    LevelCtr* nx = &ctl->lc[lvl & 1u];
+    // ---- one batch of LDS reads: what the previous level left behind its last barrier
+    const u64 al_ = in->alloc, io_ = in->pad1; const u32 nd_ = in->n_dangling, fail_ = ctl->fail, q_ = ctl->cand_q[lvl]; const int sk_ = ctl->seed_key;
+    const double dg_ = in->dangling, c_ = ctl->coef[lvl], c1_ = ctl->coef[min(lvl + 1u, L)];
+    const u64 al = uni(al_), io = uni(io_);
+    const u32 n_ent_cur = (u32)al, e_cur = (u32)(al >> 32), pu_cur = (u32)io, log_pos = (u32)(io >> 32);
+    const bool has_dang_cur = uni(nd_) != 0u;
+    const double dang_cur = has_dang_cur ? uni(dg_) : 0.0;
+    const int seed_key = uni(sk_);
+    const u32 n_rec = e_cur + (has_dang_cur ? 1u : 0u);                           // log records (= pushed edges) of this level
+    if (n_rec == 0 || uni(fail_)) return 0u;                                      // the frontier died: later levels add nothing
+    const bool last = lvl == L;                                                   // graph.h:104-110: no push from the last level
+    const u32 pu_cap = (u32)min((u64)kSkMaxPushers, p.arch_cap);                  // pusher numbers the row may hand out
+    // (fail = 1: a slab bound, counted for the host's slab sizing; anything else has its own number)
+    if ((u64)log_pos + n_rec > p.log_cap || (u64)pu_cur + n_ent_cur + 1u > pu_cap) { if (tid == 0) ctl->fail = 1; return 0u; }
+    const u32 seg_base = log_pos;
+    const u32 pu_next = pu_cur + n_ent_cur + (has_dang_cur ? 1u : 0u);            // pusher number of the NEXT list's entry 0
+    const u32 cur = lvl & 1u;                                                     // the push list this level streams (level 0 wrote list 1)
+    if (tid == 0) {
+        nx->dangling = 0.0; nx->n_dangling = 0; nx->n_rec = 0; nx->alloc = 0ull; nx->pad1 = sk_io_pack(pu_next, log_pos + n_rec);
+        ctl->tot_pu = pu_next; ctl->tot_log = log_pos + n_rec; ctl->max_e = max(ctl->max_e, e_cur);
+        ctl->lv_has_dang = has_dang_cur ? 1u : 0u; ctl->lv_dang = dang_cur;
+        if (has_dang_cur) w.arch[pu_cur + n_ent_cur] = uni(c_) * dang_cur;        // graph.h:92: the record of the mass returned to the seed
+        zstat(ctl, zLevels, 1);
+    }
+    const double cs = uni(c_) * p.sk_rscale;                                      // reserve-sketch units per unit of share
+    const double cnext = last ? 0.0 : uni(c1_);
+    SKT(ctl, 6);
+    if (last) {
+        phase_sk_stream<BLOCK, 2>(lds0, cur, n_ent_cur, e_cur, seg_base, cs, 0u, pu_cur, 1u, 0u);
+        SKT(ctl, 3);
+        return 0u;
+    }
+    // a level goes straight into the exact table while its edges would fill three quarters of it (its nodes: fewer; cap 1/2 / 0.65 / 0.8 / 1
+    // of the slots measured 23.50 / 23.42 / 23.36 / 23.85 ms)
+    const u32 direct_max = min(p.sk_direct_max, 3u * (CX / 4u));
+    // a sketch level keeps its share table (one value per pusher, one for the dangling mass) behind the slots it uses; a level
+    // with more pushers than that leaves room for (a hub's thousands of leaves all push) goes without the sketch, whatever its size
+    const u32 s_n = n_ent_cur + 1u;
+    const bool direct = n_rec <= direct_max || s_n + kMinCap > CX;
+    u32 capx = direct ? min(CX, max(kMinCap, (4u * n_rec + 3u) & ~3u)) : (CX - s_n) & ~3u;
+    const u32 cap0 = capx;                                                        // (where the share table starts)
+    // Partitions planned so that the nodes expected in the exact table -- per pushed edge what this workgroup's earlier
+    // rows tabled at this level, x 1.25 -- fit its slots: an overflowed pass costs a whole pass, a planned partition one
+    // too (measured, planning for a load of 0.5 / 0.6 / 0.7 / 0.8 / 1.0 / 1.2: 24.75 / 24.2 / 23.95 / 23.75 / 23.54 / 23.57 ms)
+    u32 P0 = 1;
+    {
+        const u32 q = uni(q_);
+        const u32 est = direct ? (n_rec > direct_max ? 2u * n_rec : 0u) : (u32)(((u64)n_rec * q) >> 10);   // (without the sketch every edge is an insert: half a table per partition)
+        while (P0 < 64u && est > P0 * capx) ++P0;                                 // (P0 > 1 is rare: no division on the common path)
+    }
+    // a small level: one wave does it, the others park at one barrier (phase_sk_solo).
+    // (a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
+    //  hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax, SURVEY.md A.1)
+    const bool solo = p.solo && direct && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&
+                      p.push_cap >= (u64)kSkSoloEdges + 4u && (u64)pu_next + kSkSoloEdges + 4u <= pu_cap &&
+                      (double)p.bt_cap >= (p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz) / (double)(1u << kUnitShift) + 4.0;
+    if (solo) {
+        if (wave_id() == 0)
+            phase_sk_solo<BLOCK>(lds0, cur, n_ent_cur, e_cur, seg_base, cs, has_dang_cur ? 1u : 0u, dang_cur, seed_key, lvl & 1u, pu_cur, pu_next, cnext);
+        GP_SYNC();
+        SKT(ctl, 1); SKT_COUNT(ctl, 13, 1);
+    } else {
+        SKT2_BEGIN(ctl);
+        if (direct && P0 == 1u) phase_sk_stream<BLOCK, 1>(lds0, cur, n_ent_cur, e_cur, seg_base, cs, capx, pu_cur, 1u, 0u);
+        else if (direct)        phase_sk_stream<BLOCK, 2>(lds0, cur, n_ent_cur, e_cur, seg_base, cs, capx, pu_cur, 1u, 0u);     // (records only: every partition is a MODE 3 pass below)
+        else                    phase_sk_stream<BLOCK, 0>(lds0, cur, n_ent_cur, e_cur, seg_base, cs, capx, pu_cur, 1u, 0u);
+        SKT2(ctl, 11);
+        GP_SYNC();
+        SKT2(ctl, 12);
+        SKT(ctl, direct ? 1 : 2); SKT_COUNT(ctl, direct ? 13 : 14, 1);
+    }
+    // Exact inserts, then SCAN.  A table that overflows is wiped and the level's candidates are walked in hash
+    // partitions (q of P, split in two in place), exactly as the general kernel refines its partitions: a sketch level
+    // re-reads its log segment, a small level re-streams its edges.
+    const bool by_log = !direct;
+    bool u_dirty = !direct, first = true;
+    u32 part = 0, np = P0;
+    bool level_done = false;
+    if (solo) {
+        if (!uni(ctl->ovf)) level_done = true;                                    // (the wave wrote the next push list and lc[lvl & 1] itself)
+        else { capx = CX; }                                                       // undone: re-stream the level (first pass below sees ctl->ovf)
+    }
+    if (!level_done)
+    for (;;) {
+        if (!(first && direct && P0 == 1u)) {
+            SKT2_BEGIN(ctl);
+            if (by_log) phase_sk_filter<BLOCK>(lds0, seg_base, n_rec, capx, pu_cur, np, part);
+            else        phase_sk_stream<BLOCK, 3>(lds0, cur, n_ent_cur, e_cur, seg_base, cs, capx, pu_cur, np, part);
+            SKT2(ctl, 2);
+            GP_SYNC();
+            SKT2(ctl, 3);
+            SKT(ctl, 4); SKT_COUNT(ctl, 11, 1);
+        }
+        first = false;
+        if (uni(ctl->ovf)) {
+            phase_sk_wipe<BLOCK>(lds0, 2u, by_log ? cap0 : CX, 0u);                              // (a sketch level's share table lives behind slot cap0)
+            GP_SYNC();
+            if (tid == 0) ctl->ovf = 0;
+            if (!by_log) capx = CX;
+            if (np < 0x10000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
+            if (tid == 0) ctl->fail = 5;                                          // (5: a level's candidates in > 65 536 partitions)
+            GP_SYNC();
+            break;
+        }
+        const bool final_part = np == P0 && part + 1u == P0;                      // nothing reads the sketch after this partition
+        SKT2_BEGIN(ctl);
+        phase_sk_scan<BLOCK>(lds0, capx, lvl & 1u, cur ^ 1u, final_part && u_dirty ? s_n : 0u, pu_next, cnext);
+        if (final_part) u_dirty = false;
+        SKT2(ctl, 9);
+        GP_SYNC();
+        SKT2(ctl, 10);
+        SKT(ctl, 5); SKT_COUNT(ctl, 12, 1);
+        if (uni(ctl->fail)) break;
+        while (np > P0 && (part & 1u)) { part >>= 1; np >>= 1; }
+        ++part;
+        if (np == P0 && part == P0) break;
+    }
+    if (u_dirty) {                                                                // (a split partition walk of a sketch level)
+        phase_sk_wipe<BLOCK>(lds0, 3u, s_n, cap0);
+        GP_SYNC();
+    }
+    if (uni(ctl->fail)) return 0u;
+    if (tid == 0 && !direct) {                                                    // nodes the exact table held per pushed edge, x 1.25, decaying maximum
+        const u32 obs = min(2048u, (u32)(1280.0f * (float)nx->n_rec * __frcp_rn((float)n_rec)) + 8u);
+        const u32 old_q = ctl->cand_q[lvl];
+        ctl->cand_q[lvl] = max(obs, old_q - (old_q >> 3));
+    }
+    return 1u;
 }
 
 template <int BLOCK>
@@ -940,25 +1199,17 @@ __device__ __forceinline__ void gfpush_sk_rows()
     const SkView w = sk_view(p, lds0);
     CtlS* ctl = w.ctl;
     const int tid = threadIdx.x;
-    const u32 CX = w.CX;
-    sk_wipe<BLOCK>(w);
+    phase_sk_wipe<BLOCK>(lds0, 1u, 0u, 0u);
     if (tid < 8) { ctl->st[tid] = 0; ctl->st_row[tid] = 0; }
 #ifdef GP_SK_TIMING
     if (tid < 16) ctl->tacc[tid] = 0;
     if (tid < 14) ctl->tacc2[tid] = 0;
 #endif
     if (tid < kSkMaxCoef) { ctl->cand_q[tid] = 0; if (tid < p.n_coef) ctl->coef[tid] = p.coef[tid]; }
+    if (tid == 0) { ctl->max_e = 0; ctl->max_log = 0; }
     const long long n_rows = p.n_seeds;
-    u32 max_e = 0, max_log = 0;
-    const int L = p.n_coef - 1;
-    // a level goes straight into the exact table while its edges would fill three quarters of it (its nodes: fewer; cap 1/2 / 0.65 / 0.8 / 1
-    // of the slots measured 23.50 / 23.42 / 23.36 / 23.85 ms)
-    const u32 direct_max = min(p.sk_direct_max, 3u * (CX / 4u));
-    // (a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
-    //  hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax, SURVEY.md A.1)
-    const double solo_e_bound = p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz;
-    const u32 pu_cap = (u32)min((u64)kSkMaxPushers, p.arch_cap);                      // pusher numbers the row may hand out
-    const u32 top_region = 4u * w.MU + 12u * CX;
+    const u32 L = (u32)p.n_coef - 1u;
+    const u32 top_region = 4u * w.MU + 12u * w.CX;
 
     for (;;) {
         GP_SYNC();
@@ -975,178 +1226,20 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (tid == 0) { __hip_atomic_fetch_add(&ctl->st[zFailed], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p.out_filled) p.out_filled[row] = 0; }
             continue;
         }
-        const u32 seed_unit = uni(p.node_pos[seed]);
-        const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - uni((u32)p.indptr[seed]);
-        const u32 s_start = seed_unit << kSkUnitShift;
-        const int seed_key = (int)(seed_unit | (min(seed_deg, p.deg_sat) << p.deg_shift));
-
-        u32 n_ent_cur = 0, e_cur = 0, log_pos = 1;
-        double dang_cur = 0.0; bool has_dang_cur = false;
-        int cur = 1;
-        u32 pu_cur = 1;                                 // pusher number of the current list's entry 0 (number 0: the seed's own record)
-        // ---- level 0: the frontier is { seed : 1.0 } (graph.h:81): its record, push test and push-list entry directly
-        {
-            PushEntry* push1 = w.push2 + (size_t)1 * p.push_cap;
-            u32* bt1 = w.bt2 + (size_t)1 * p.bt_cap;
-            if (tid == 0) {
-                if (p.log_cap > 0 && pu_cap >= 2u) {                                               // graph.h:90
-                    w.log_key[0] = seed_key; w.log_pu[0] = 0; w.arch[0] = ctl->coef[0];
-                } else ctl->fail = 1;
-                lds_add_u32(&w.R[((u32)seed_key * kSkMulA) >> w.shR], fx_up(ctl->coef[0] * p.sk_rscale));
-                zstat(ctl, zLevels, 1);
-            }
-            if (L > 0) {
-                if (seed_deg == 0) { dang_cur = 1.0; has_dang_cur = true; }           // graph.h:91-93
-                else if (1.0 >= p.rmax * (double)seed_deg) {                          // graph.h:94
-                    const double share = 1.0 / (double)seed_deg;                      // graph.h:95
-                    if (tid == 0) { zstat(ctl, zPush, 1); zstat(ctl, zEdges, seed_deg); }
-                    if (share != 0.0) {
-                        e_cur = seed_deg; n_ent_cur = 1;
-                        if (tid == 0) {
-                            if (p.push_cap > 0 && pu_cap >= 2u) {
-                                PushEntry pe; pe.rel = s_start; pe.off = 0; pe.share = share; push1[0] = pe;
-                                w.arch[1] = ctl->coef[1] * share;
-                            } else ctl->fail = 1;
-                        }
-                        const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
-                        if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
-                        else for (u32 m = (u32)tid; m < units; m += BLOCK) { bt1[m] = 0u; if (m < w.bt_l_cap) w.bt_l[m] = 0u; }
-                    }
-                }
-            }
-            GP_SYNC();
-            SKT(ctl, 0); SKT_COUNT(ctl, 15, 1);
-        }
-        for (int lvl = 1; lvl <= L; ++lvl) {
-            const u32 n_rec = e_cur + (has_dang_cur ? 1u : 0u);                       // log records (= pushed edges) of this level
-            if (n_rec == 0 || uni(ctl->fail)) break;                                  // the frontier died: later levels add nothing
-            const bool last = lvl == L;                                               // graph.h:104-110: no push from the last level
-            max_e = max(max_e, e_cur);
-            // (fail = 1: a slab bound, counted for the host's slab sizing; anything else has its own number)
-            if ((u64)log_pos + n_rec > p.log_cap || (u64)pu_cur + n_ent_cur + 1u > pu_cap) { if (tid == 0) ctl->fail = 1; GP_SYNC(); break; }
-            const u32 seg_base = log_pos;
-            const u32 pu_next = pu_cur + n_ent_cur + (has_dang_cur ? 1u : 0u);        // ... of the NEXT list's entry 0
-            LevelCtr* nx = &ctl->lc[lvl & 1];
-            if (tid == 0) {
-                nx->dangling = 0.0; nx->n_dangling = 0; nx->n_rec = 0; nx->alloc = 0ull;
-                if (has_dang_cur) w.arch[pu_cur + n_ent_cur] = ctl->coef[lvl] * dang_cur;         // graph.h:92: the record of the mass returned to the seed
-                zstat(ctl, zLevels, 1);
-            }
-            log_pos += n_rec;
-            const double cs = uni(ctl->coef[lvl]) * p.sk_rscale;                      // reserve-sketch units per unit of share
-            const double cnext = last ? 0.0 : uni(ctl->coef[lvl + 1]);
-            SKT(ctl, 6);
-            if (last) {
-                phase_sk_stream<BLOCK, 2>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, 0u, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, 1u, 0u);
-                SKT(ctl, 3);
-                pu_cur = pu_next;
-                break;
-            }
-            // a sketch level keeps its share table (one value per pusher, one for the dangling mass) behind the slots it uses; a level
-            // with more pushers than that leaves room for (a hub's thousands of leaves all push) goes without the sketch, whatever its size
-            const u32 s_n = n_ent_cur + 1u;
-            const bool direct = n_rec <= direct_max || s_n + kMinCap > CX;
-            u32 capx = direct ? min(CX, max(kMinCap, (4u * n_rec + 3u) & ~3u)) : (CX - s_n) & ~3u;
-            const u32 cap0 = capx;                                                    // (where the share table starts)
-            // Partitions planned so that the nodes expected in the exact table -- per pushed edge what this workgroup's earlier
-            // rows tabled at this level, x 1.25 -- fit its slots: an overflowed pass costs a whole pass, a planned partition one
-            // too (measured, planning for a load of 0.5 / 0.6 / 0.7 / 0.8 / 1.0 / 1.2: 24.75 / 24.2 / 23.95 / 23.75 / 23.54 / 23.57 ms)
-            u32 P0 = 1;
-            if (!direct) {
-                const u32 q = uni(ctl->cand_q[lvl]);
-                const u32 est = (u32)(((u64)n_rec * q) >> 10);
-                if (q != 0 && est > capx) P0 = min(64u, (est + capx - 1u) / capx);
-            } else if (n_rec > direct_max) P0 = min(64u, (n_rec + CX / 2u - 1u) / (CX / 2u));        // (every edge is an insert: half a table per partition)
-            // a small level: one wave does it, the others park at one barrier (phase_sk_solo)
-            const bool solo = p.solo && direct && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&
-                              p.push_cap >= (u64)kSkSoloEdges + 4u && (u64)pu_next + kSkSoloEdges + 4u <= pu_cap &&
-                              (double)p.bt_cap >= solo_e_bound / (double)(1u << kUnitShift) + 4.0;
-            if (solo) {
-                if (wave_id() == 0)
-                    phase_sk_solo<BLOCK>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, has_dang_cur ? 1u : 0u, dang_cur, seed_key, (u32)(lvl & 1), pu_cur, pu_next, cnext);
-                GP_SYNC();
-                SKT(ctl, 1); SKT_COUNT(ctl, 13, 1);
-            } else {
-            SKT2_BEGIN(ctl);
-            if (direct) phase_sk_stream<BLOCK, 1>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, P0, 0u);
-            else        phase_sk_stream<BLOCK, 0>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, 1u, 0u);
-            SKT2(ctl, 11);
-            GP_SYNC();
-            SKT2(ctl, 12);
-            SKT(ctl, direct ? 1 : 2); SKT_COUNT(ctl, direct ? 13 : 14, 1);
-            }
-            // Exact inserts, then SCAN.  A table that overflows is wiped and the level's candidates are walked in hash
-            // partitions (q of P, split in two in place), exactly as the general kernel refines its partitions: a sketch level
-            // re-reads its log segment, a small level re-streams its edges.
-            const bool by_log = !direct;
-            bool u_dirty = !direct, first = true;
-            u32 part = 0, np = P0;
-            bool level_done = false;
-            if (solo) {
-                if (!uni(ctl->ovf)) level_done = true;                                // (the wave wrote the next push list and lc[lvl & 1] itself)
-                else { capx = CX; }                                                   // undone: re-stream the level (first pass below sees ctl->ovf)
-            }
-            if (!level_done)
-            for (;;) {
-                if (!(first && direct)) {
-                    SKT2_BEGIN(ctl);
-                    if (by_log) phase_sk_filter<BLOCK>(lds0, seg_base, n_rec, capx, pu_cur, np, part);
-                    else        phase_sk_stream<BLOCK, 3>(lds0, (u32)cur, n_ent_cur, e_cur, seg_base, cs, capx, has_dang_cur ? 1u : 0u, dang_cur, seed_key, pu_cur, np, part);
-                    SKT2(ctl, 2);
-                    GP_SYNC();
-                    SKT2(ctl, 3);
-                    SKT(ctl, 4); SKT_COUNT(ctl, 11, 1);
-                }
-                first = false;
-                if (uni(ctl->ovf)) {
-                    sk_wipe_x<BLOCK>(w, by_log ? cap0 : CX);                          // (a sketch level's share table lives behind slot cap0)
-                    GP_SYNC();
-                    if (tid == 0) ctl->ovf = 0;
-                    if (!by_log) capx = CX;
-                    if (np < 0x10000u) { part *= 2; np *= 2; GP_SYNC(); continue; }
-                    if (tid == 0) ctl->fail = 5;                                      // (5: a level's candidates in > 65 536 partitions)
-                    GP_SYNC();
-                    break;
-                }
-                const bool final_part = np == P0 && part + 1u == P0;                  // nothing reads the sketch after this partition
-                SKT2_BEGIN(ctl);
-                phase_sk_scan<BLOCK>(lds0, capx, (u32)(lvl & 1), (u32)(cur ^ 1), final_part && u_dirty ? s_n : 0u, pu_next, cnext);
-                if (final_part) u_dirty = false;
-                SKT2(ctl, 9);
-                GP_SYNC();
-                SKT2(ctl, 10);
-                SKT(ctl, 5); SKT_COUNT(ctl, 12, 1);
-                if (uni(ctl->fail)) break;
-                while (np > P0 && (part & 1u)) { part >>= 1; np >>= 1; }
-                ++part;
-                if (np == P0 && part == P0) break;
-            }
-            if (u_dirty) {                                                            // (a split partition walk of a sketch level)
-                typedef u32 u4 __attribute__((ext_vector_type(4)));
-                const u4 z = {0u, 0u, 0u, 0u};
-                for (u32 i = 4u * (u32)tid; i < w.MU; i += 4u * BLOCK) *(u4*)&w.U[i] = z;
-                for (u32 i = (u32)tid; i < s_n; i += BLOCK) w.xvals[cap0 + i] = 0.0;
-                GP_SYNC();
-            }
-            if (uni(ctl->fail)) break;
-            if (tid == 0 && !direct) {                                                // nodes the exact table held per pushed edge, x 1.25, decaying maximum
-                const u32 obs = min(2048u, (u32)(1280.0f * (float)nx->n_rec * __frcp_rn((float)n_rec)) + 8u);
-                const u32 old_q = ctl->cand_q[lvl];
-                ctl->cand_q[lvl] = max(obs, old_q - (old_q >> 3));
-            }
-            { const u64 al = uni(nx->alloc); n_ent_cur = (u32)al; e_cur = (u32)(al >> 32); }
-            has_dang_cur = uni(nx->n_dangling) != 0; dang_cur = has_dang_cur ? uni(nx->dangling) : 0.0;
-            cur ^= 1;
-            pu_cur = pu_next;
-        }
+        phase_sk_seed<BLOCK>(lds0, seed);
+        GP_SYNC();
+        SKT(ctl, 0); SKT_COUNT(ctl, 15, 1);
+        for (u32 lvl = 1; lvl <= L; ++lvl)
+            if (!uni(phase_sk_level<BLOCK>(lds0, lvl))) break;
         GP_SYNC();
         SKT(ctl, 6);
-        max_log = max(max_log, log_pos);
-                if (!uni(ctl->fail)) {
+        if (!uni(ctl->fail)) {
+            const u32 n_pu = uni(ctl->tot_pu), n_log = uni(ctl->tot_log);
+            if (tid == 0) ctl->max_log = max(ctl->max_log, n_log);
             // (T beside at least half of the aggregation table TOP-K has without it; else the gathering form)
-            if (2u * sk_top_slots(top_region, pu_cur, (u32)p.K) >= sk_top_slots(top_region, 0u, (u32)p.K))
-                 phase_sk_topk<BLOCK, false>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, pu_cur, log_pos);
-            else phase_sk_topk<BLOCK, true>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, pu_cur, log_pos);
+            if (2u * sk_top_slots(top_region, n_pu, (u32)p.K) >= sk_top_slots(top_region, 0u, (u32)p.K))
+                 phase_sk_topk<BLOCK, false>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, n_pu, n_log);
+            else phase_sk_topk<BLOCK, true>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, n_pu, n_log);
         }
         GP_SYNC();
         if (uni(ctl->fail)) {
@@ -1156,13 +1249,13 @@ __device__ __forceinline__ void gfpush_sk_rows()
                 p.retry_list[i] = (u32)row;
                 if (ctl->fail == 1) __hip_atomic_fetch_add(&p.counters[kSkSlabFails], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifndef GP_SK_TIMING
-                __hip_atomic_fetch_add(&p.counters[kDiag0 + min(ctl->fail, 7u)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // why rows left (diag_sub[1..6])
+                __hip_atomic_fetch_add(&p.counters[kDiag0 + min(ctl->fail, 7u)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // why rows left (diag_sub[1..5])
 #endif
             }
             if (tid < 8) ctl->st_row[tid] = 0;
         } else if (tid < 8) { ctl->st[tid] += ctl->st_row[tid]; ctl->st_row[tid] = 0; }
         GP_SYNC();
-        sk_wipe<BLOCK>(w);                                                            // TOP-K used the level tables' bytes; R is per row
+        phase_sk_wipe<BLOCK>(lds0, 1u, 0u, 0u);                                                            // TOP-K used the level tables' bytes; R is per row
         SKT(ctl, 10);
     }
     GP_SYNC();
@@ -1171,8 +1264,8 @@ __device__ __forceinline__ void gfpush_sk_rows()
 #pragma unroll
         for (int i = 0; i < zNumStats; ++i)
             if (ctl->st[i]) __hip_atomic_fetch_add(&p.counters[dst[i]], ctl->st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (max_e) __hip_atomic_fetch_max(&p.counters[kMaxLevelEdges], (u64)max_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (max_log) __hip_atomic_fetch_max(&p.counters[kMaxLogRecords], (u64)max_log, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ctl->max_e) __hip_atomic_fetch_max(&p.counters[kMaxLevelEdges], (u64)ctl->max_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ctl->max_log) __hip_atomic_fetch_max(&p.counters[kMaxLogRecords], (u64)ctl->max_log, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef GP_SK_TIMING
         for (int i = 0; i < 16; ++i) __hip_atomic_fetch_add(&p.counters[kDiag0 + i], ctl->tacc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = 0; i < 14; ++i) __hip_atomic_fetch_add(&p.counters[kDiagX0 + i], ctl->tacc2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -152,37 +152,44 @@ __device__ __forceinline__ u32 sk_degree(KP p, u32 key) {
     return (u32)(p.indptr[node + 1] - p.indptr[node]);
 }
 
-// Walks log records [0, n) in groups of 256 (four 64-lane windows), groups dealt to the waves round robin; f(key[4], pusher[4],
-// first record of the group) runs while the NEXT group's eight loads are in flight.  Lanes past n get key -1 (n >= 1).
-// NT: the records are not needed again (TOP-K's sweep) -- the loads carry the non-temporal hint, so the lines leave the L2 first.
+// Walks the log records [first, end) of the workgroup's log in groups of 256, groups dealt to the waves round robin; f(key[4],
+// pusher[4], valid[4]) runs while the NEXT group's loads are in flight.  A lane takes FOUR CONSECUTIVE records of a group with one
+// 16-byte and one 8-byte load (groups start at multiples of four records of the slab, which is 16-byte aligned: two load
+// instructions per group instead of eight); "window" q of a group = record 4 * lane + q of every lane.  Records outside [first, end)
+// come back with key -1 (end > first).  (every load is unconditional -- a lane past the end re-reads the last chunk and is masked
+// when the group is consumed: a conditional load merges control flow between issue and use, and the compiler then waits for ALL
+// loads in flight.)  NT: the records are not needed again (TOP-K's sweep) -- the loads carry the non-temporal hint, so the lines
+// leave the L2 first.
 template <int BLOCK, bool NT = false, class F>
-__device__ __forceinline__ void log_groups(const int* lk, const unsigned short* lp, u32 n, F f)
+__device__ __forceinline__ void log_groups(const int* lk, const unsigned short* lp, u32 first, u32 end, F f)
 {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef u32 u2 __attribute__((ext_vector_type(2)));
     constexpr u32 kStride = (BLOCK / 64) * 256u;
     const u32 lane = threadIdx.x & 63u;
-    u32 g = wave_id() * 256u;
-    if (g >= n) return;
-    // (every load is unconditional -- a lane past n re-reads the last record and is masked when the group is consumed: a
-    //  conditional load merges control flow between issue and use, and the compiler then waits for ALL loads in flight)
-    int kn[4]; u32 pn[4];
+    u32 g = (first & ~3u) + wave_id() * 256u;
+    if (g >= end) return;
+    const u32 last_chunk = (end - 1u) & ~3u;
+    i4 kn; u2 pn;
     auto load = [&](u32 g0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32 i = min(g0 + 64u * (u32)q + lane, n - 1u);
-            if (NT) { kn[q] = __builtin_nontemporal_load(&lk[i]); pn[q] = __builtin_nontemporal_load(&lp[i]); }
-            else    { kn[q] = lk[i]; pn[q] = lp[i]; }
-        }
+        const u32 i = min(g0 + 4u * lane, last_chunk);
+        if (NT) { kn = __builtin_nontemporal_load((const i4*)&lk[i]); pn = __builtin_nontemporal_load((const u2*)&lp[i]); }
+        else    { kn = *(const i4*)&lk[i]; pn = *(const u2*)&lp[i]; }
     };
     load(g);
     for (;;) {
         int k[4]; u32 pu[4];
+        const u32 i0 = g + 4u * lane;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const bool in = g + 64u * (u32)q + lane < n; k[q] = in ? kn[q] : -1; pu[q] = in ? pn[q] : 0u; }
-        const u32 cur = g;
+        for (int q = 0; q < 4; ++q) {
+            const bool in = i0 + (u32)q >= first && i0 + (u32)q < end;
+            k[q] = in ? kn[q] : -1;
+            pu[q] = in ? (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu : 0u;
+        }
         g += kStride;
-        const bool more = g < n;                                      // wave-uniform
+        const bool more = g < end;                                    // wave-uniform
         if (more) load(g);
-        f(k, pu, cur);
+        f(k, pu);
         if (!more) break;
     }
 }
@@ -430,7 +437,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
     const double* S = w.xvals + capx;
     u32 n_cand = 0;
     SKT2(w.ctl, 0);
-    log_groups<BLOCK>(w.log_key + seg_base, w.log_pu + seg_base, n, [&](const int (&k)[4], const u32 (&pu)[4], u32 g0) {
+    log_groups<BLOCK>(w.log_key, w.log_pu, seg_base, seg_base + n, [&](const int (&k)[4], const u32 (&pu)[4]) {
         u32 cell[4]; double s[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                                                 // eight lookups in flight
@@ -439,7 +446,6 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (g0 + 64u * (u32)q >= n) break;                                        // wave-uniform
             bool cand = k[q] >= 0;
             if (cand) {
                 const u32 dq = (u32)k[q] >> dshift;                                   // min(deg, deg_sat); 0: dangling, always exact
@@ -688,13 +694,17 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
 }
 
 // ---------------------------------------------------------------- TOP-K
-struct SkTop {                             // TOP-K's carving of the LDS behind the control block
+// TOP-K's carving of the LDS behind the control block and R: { T f64[pushers of the row] | aggregation values f64[CA] | keys i32[CA] |
+// tie Cand[256] | sel Cand[K] } over the dead level tables.  The table takes every byte that is left: a table at X's own size
+// (2 960 slots, which the levels leave empty: no wipe) measured +4.5 % kernel time against ~4 100 slots -- one insert that runs
+// into the probe limit costs the row a whole partitioned round.
+struct SkTop {
     u32* R; u32 MR, shR; double* T; double* avals; int* akeys; u32 CA; Cand* tie; Cand* sel; u32* fine;
 };
-// bytes of the region TOP-K carves / slots of the aggregation table that remain beside T for n_pu pushers (0: T does not fit)
+// slots of the aggregation table that remain beside T for n_pu pushers (0: T does not fit)
 __device__ __forceinline__ u32 sk_top_slots(u32 region_bytes, u32 n_pu, u32 K) {
     const u32 fixed = 8u * ((n_pu + 1u) & ~1u) + 16u * (kSkTie + K);
-    return region_bytes > fixed ? ((region_bytes - fixed) / 12u) & ~3u : 0u;
+    return region_bytes > fixed ? ((region_bytes - fixed) / 12u) & ~7u : 0u;
 }
 __device__ __forceinline__ SkTop sk_top(KP p, const SkView& w, u32 n_pu) {
     SkTop t;
@@ -712,108 +722,12 @@ __device__ __forceinline__ SkTop sk_top(KP p, const SkView& w, u32 n_pu) {
     return t;
 }
 
-// Select the K largest (value desc, column asc) positive totals of the aggregation table into sel[0 .. need) (graph.h:111-121),
-// rank them (thread i < need: my_rank = position of sel[i] in the output order) and note the smallest in ctl->kth_bits.  Returns need = min(K, positive totals); 0xFFFFFFFF: the row must leave
-// (more than kSkTie near-ties, or a total outside [2^-63, 2)).  Every thread of the workgroup calls this.
+// The tail of both selects: the entries of the K-th bin ranked among themselves (value desc, node id asc), then all selected ranked
+// (thread i < need: my_rank = position of sel[i] in the output order); the smallest selected value goes to ctl->kth_bits.
 template <int BLOCK>
-__device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& my_rank)
+__device__ __forceinline__ void sk_rank_selected(KP p, CtlS* ctl, const SkTop& t, u32 need, bool take_all, u32& my_rank)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const u32 wave = wave_id(), K = (u32)p.K, CA = t.CA;
-    const int* akeys = t.akeys; const double* avals = t.avals;
-    for (u32 i = tid; i < CA; i += BLOCK) {
-        if (akeys[i] != kEmpty) {
-            const double v = avals[i];
-            if (v > 0.0) {
-                const int e = 1023 - (int)((u64)__double_as_longlong(v) >> 52);
-                if ((u32)e < 64u) lds_add_u32(&ctl->bcnt[e], 1u); else ctl->tk_wide = 1u;
-            }
-        }
-    }
-    GP_SYNC();
-    if (uni(ctl->tk_wide)) return 0xFFFFFFFFu;
-    if (wave == 0) {                                                                  // lane = binade, 0 holds the largest values
-        const SerialSection ahead;
-        const u32 cn = ctl->bcnt[lane];
-        const u32 incl = wave_incl_scan_dpp(cn);
-        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        const u32 want = min(K, total);
-        const u64 mk = __ballot(incl >= want && want != 0u);
-        const int bl = mk ? __ffsll((long long)mk) - 1 : 63;
-        if (lane == bl) { ctl->tk_bin = (u32)bl; ctl->tk_above = incl - cn; ctl->tk_count = cn; ctl->tk_total = total; }
-    }
-    GP_SYNC();
-    const u32 total = uni(ctl->tk_total), b_sel = uni(ctl->tk_bin);
-    u32 above = uni(ctl->tk_above), cnt_b = uni(ctl->tk_count);
-    const u32 need = min(K, total);
-    GP_SYNC();
-    if (need == 0) return 0;
-    // While more than kSkTie entries crowd the bucket of the K-th entry, narrow it: 8 more bits of the value at a time (larger
-    // first), then -- a FLAT row: a seed whose neighbour is a hub hands thousands of nodes totals that differ by summation-order
-    // ulps or not at all -- 8 bits of the node id at a time (smaller first: the output order is value desc, column asc).
-    // The bucket is { entries with (bits >> vshift) == vpre and, once vshift == 0, (id >> ishift) == ipre }.
-    u32 vshift = 52; u64 vpre = (u64)(1023u - b_sel);
-    u32 ishift = 8u * (u32)(((int)p.deg_shift + 7) / 8), ipre = 0;
-    while (above + cnt_b > need && cnt_b > kSkTie && (vshift > 0u || ishift > 0u)) {
-        const bool by_value = vshift > 0u;
-        const u32 ds = by_value ? min(8u, vshift) : 8u;
-        const u32 vs_hi = vshift, is_hi = ishift;                                     // the bucket being split
-        if (by_value) vshift -= ds; else ishift -= ds;
-        for (u32 i = tid; i < 256u; i += BLOCK) t.fine[i] = 0;
-        GP_SYNC();
-        for (u32 i = tid; i < CA; i += BLOCK) {
-            if (akeys[i] != kEmpty && avals[i] > 0.0) {
-                const u64 bits = (u64)__double_as_longlong(avals[i]);
-                const u32 id = (u32)akeys[i] & p.node_mask;
-                if ((bits >> vs_hi) == vpre && (by_value || is_hi >= 32u || (id >> is_hi) == ipre)) {
-                    const u32 dg = by_value ? (u32)(bits >> vshift) & ((1u << ds) - 1u) : (id >> ishift) & 255u;
-                    lds_add_u32(&t.fine[by_value ? 255u - dg : dg], 1u);             // bin order = output order
-                }
-            }
-        }
-        GP_SYNC();
-        if (wave == 0) {                                                              // lane j owns bins [4 j, 4 j + 4), best first
-            u32 cnt[4], sum = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { cnt[j] = t.fine[4 * lane + j]; sum += cnt[j]; }
-            const u32 incl = wave_incl_scan_dpp(sum) + above;                         // entries in bins <= 4 lane + 3, and everything above the bucket
-            const u64 m = __ballot(incl >= need);
-            const int cl = m ? __ffsll((long long)m) - 1 : 63;
-            if (lane == cl) {
-                u32 acc = incl - sum; int js = 3;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { if (acc + cnt[j] >= need) { js = j; break; } acc += cnt[j]; }
-                ctl->tk_dig = 4u * (u32)lane + (u32)js; ctl->tk_above = acc; ctl->tk_count = cnt[js];
-            }
-        }
-        GP_SYNC();
-        const u32 bin = uni(ctl->tk_dig);
-        above = uni(ctl->tk_above); cnt_b = uni(ctl->tk_count);
-        if (by_value) vpre = (vpre << ds) | (u64)(255u - bin) ; else ipre = (ipre << 8) | bin;
-        GP_SYNC();
-    }
-    if (above + cnt_b > need && cnt_b > kSkTie) return 0xFFFFFFFFu;                   // (cannot happen: ids are unique)
-    // collect: strictly above the K-th bin -> sel; inside it -> tie (all of it goes to sel when it fits exactly)
-    const bool take_all = above + cnt_b <= need;
-    for (u32 base = 0; base < CA; base += BLOCK) {
-        const u32 i = base + (u32)tid;
-        bool is_sel = false, is_t = false;
-        Cand cd; cd.bits = 0; cd.key = 0; cd.pad = 0;
-        if (i < CA && akeys[i] != kEmpty && avals[i] > 0.0) {
-            cd.bits = (u64)__double_as_longlong(avals[i]); cd.key = akeys[i];         // (the PACKED key: a merged entry goes back into a table)
-            const u32 id = (u32)cd.key & p.node_mask;
-            const u64 vb = cd.bits >> vshift;
-            const bool v_eq = vb == vpre;
-            const bool in_bin = v_eq && (ishift >= 32u || (id >> ishift) == ipre);
-            const bool over = vb > vpre || (v_eq && ishift < 32u && (id >> ishift) < ipre);
-            is_sel = over || (in_bin && take_all); is_t = in_bin && !take_all;
-        }
-        const u32 si = wave_alloc1(&ctl->n_sel, is_sel, lane);
-        if (is_sel) t.sel[si] = cd;
-        const u32 ti = wave_alloc1(&ctl->n_tie, is_t, lane);
-        if (is_t) t.tie[ti] = cd;
-    }
-    GP_SYNC();
+    const int tid = threadIdx.x;
     if (!take_all) {
         const u32 nt = uni(ctl->n_tie), n0 = uni(ctl->n_sel), want = need - n0;        // nt == cnt_b <= kSkTie
         // ties inside the bin are ordered like the output: value desc, then NODE id asc (the packed key's low bits)
@@ -843,11 +757,130 @@ __device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& m
         if (rank + 1u == need) ctl->kth_bits = cd.bits;
     }
     GP_SYNC();
+}
+
+// Select the K largest (value desc, column asc) positive totals of the aggregation table into sel[0 .. need) (graph.h:111-121),
+// rank them (thread i < need: my_rank = position of sel[i] in the output order) and note the smallest in ctl->kth_bits.  Returns
+// need = min(K, positive totals); 0xFFFFFFFF: the row must leave (a total outside [2^-63, 2)).  Every thread of the workgroup calls
+// this.  Passes walk the table four slots per lane and step (128-bit LDS reads); every wave reads the small histograms itself, so no
+// result is broadcast through LDS behind extra barriers; and the bucket of the K-th entry is narrowed 8 value bits at a time until
+// a handful is left to rank by comparison (one binade holds a hundred entries of a MAG row: ranking them cost more than a pass).
+constexpr u32 kSkNarrow = 16;
+template <class F>
+__device__ __forceinline__ void sk_table_walk(const SkTop& t, int block, F f)      // f(key, value bits) for every positive entry
+{
+    typedef int    i4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    for (u32 s0 = 4u * threadIdx.x; s0 < t.CA; s0 += 4u * (u32)block) {              // (CA % 4 == 0)
+        const i4 kk = *(const i4*)&t.akeys[s0];
+        if (kk.x == kEmpty && kk.y == kEmpty && kk.z == kEmpty && kk.w == kEmpty) continue;
+        const d2 va = *(const d2*)&t.avals[s0], vb = *(const d2*)&t.avals[s0 + 2];
+        if (kk.x != kEmpty && va.x > 0.0) f(kk.x, (u64)__double_as_longlong(va.x));
+        if (kk.y != kEmpty && va.y > 0.0) f(kk.y, (u64)__double_as_longlong(va.y));
+        if (kk.z != kEmpty && vb.x > 0.0) f(kk.z, (u64)__double_as_longlong(vb.x));
+        if (kk.w != kEmpty && vb.y > 0.0) f(kk.w, (u64)__double_as_longlong(vb.y));
+    }
+}
+template <int BLOCK>
+__device__ __forceinline__ u32 sk_select(KP p, CtlS* ctl, const SkTop& t, u32& my_rank)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 K = (u32)p.K;
+    sk_table_walk(t, BLOCK, [&](int, u64 bits) {
+        const int e = 1023 - (int)(bits >> 52);
+        if ((u32)e < 64u) lds_add_u32(&ctl->bcnt[e], 1u); else ctl->tk_wide = 1u;
+    });
+    GP_SYNC();
+    if (uni(ctl->tk_wide)) return 0xFFFFFFFFu;
+    u32 above, cnt_b, b_sel, need;
+    {                                                                                 // lane = binade, 0 holds the largest values
+        const u32 cn = ctl->bcnt[lane];
+        const u32 incl = wave_incl_scan_dpp(cn);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        need = min(K, total);
+        if (need == 0) return 0;
+        const u64 mk = __ballot(incl >= need);
+        b_sel = (u32)(__ffsll((long long)mk) - 1);
+        above = (u32)__builtin_amdgcn_readlane((int)(incl - cn), (int)b_sel);
+        cnt_b = (u32)__builtin_amdgcn_readlane((int)cn, (int)b_sel);
+    }
+    // While more than kSkNarrow entries crowd the bucket of the K-th entry, narrow it: 8 more bits of the value at a time (larger
+    // first), then -- a FLAT row: a seed whose neighbour is a hub hands thousands of nodes totals that differ by summation-order
+    // ulps or not at all -- 8 bits of the node id at a time (smaller first: the output order is value desc, column asc).
+    // The bucket is { entries with (bits >> vshift) == vpre and, once vshift == 0, (id >> ishift) == ipre }.  Two histogram
+    // buffers alternate, so the next round's zeroing never meets this round's readers.
+    u32 vshift = 52; u64 vpre = (u64)(1023u - b_sel);
+    u32 ishift = 8u * (u32)(((int)p.deg_shift + 7) / 8), ipre = 0, buf = 0;
+    while (above + cnt_b > need && cnt_b > kSkNarrow && (vshift > 0u || ishift > 0u)) {
+        const bool by_value = vshift > 0u;
+        const u32 ds = by_value ? min(8u, vshift) : 8u;
+        const u32 vs_hi = vshift, is_hi = ishift;                                     // the bucket being split
+        if (by_value) vshift -= ds; else ishift -= ds;
+        u32* fine = t.fine + 256u * buf; buf ^= 1u;
+        for (u32 i = tid; i < 256u; i += BLOCK) fine[i] = 0;
+        GP_SYNC();
+        sk_table_walk(t, BLOCK, [&](int key, u64 bits) {
+            const u32 id = (u32)key & p.node_mask;
+            if ((bits >> vs_hi) == vpre && (by_value || is_hi >= 32u || (id >> is_hi) == ipre)) {
+                const u32 dg = by_value ? (u32)(bits >> vshift) & ((1u << ds) - 1u) : (id >> ishift) & 255u;
+                lds_add_u32(&fine[by_value ? 255u - dg : dg], 1u);                   // bin order = output order
+            }
+        });
+        GP_SYNC();
+        {                                                                             // lane j owns bins [4 j, 4 j + 4), best first
+            u32 c4[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c4[j] = fine[4 * lane + j]; sum += c4[j]; }
+            const u32 incl = wave_incl_scan_dpp(sum) + above;                         // entries in bins <= 4 lane + 3, and everything above the bucket
+            const u64 m = __ballot(incl >= need);
+            const int cl = m ? __ffsll((long long)m) - 1 : 63;
+            u32 acc = incl - sum, cj = c4[3]; int js = 3;                            // (lane cl always finds its bin)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (acc + c4[j] >= need) { js = j; cj = c4[j]; break; } acc += c4[j]; }
+            const u32 bin = 4u * (u32)cl + (u32)__builtin_amdgcn_readlane(js, cl);
+            above = (u32)__builtin_amdgcn_readlane((int)acc, cl);
+            cnt_b = (u32)__builtin_amdgcn_readlane((int)cj, cl);
+            if (by_value) vpre = (vpre << ds) | (u64)(255u - bin); else ipre = (ipre << 8) | bin;
+        }
+    }
+    if (above + cnt_b > need && cnt_b > kSkTie) return 0xFFFFFFFFu;                   // (cannot happen: ids are unique)
+    // collect: strictly above the K-th bucket -> sel; inside it -> tie (all of it goes to sel when it fits exactly)
+    const bool take_all = above + cnt_b <= need;
+    {
+        typedef int    i4 __attribute__((ext_vector_type(4)));
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        for (u32 base = 0; base < t.CA; base += 4u * BLOCK) {
+            const u32 s0 = base + 4u * (u32)tid;
+            i4 kk = {kEmpty, kEmpty, kEmpty, kEmpty}; d2 va = {0.0, 0.0}, vb = {0.0, 0.0};
+            if (s0 < t.CA) { kk = *(const i4*)&t.akeys[s0]; va = *(const d2*)&t.avals[s0]; vb = *(const d2*)&t.avals[s0 + 2]; }
+            const double v[4] = {va.x, va.y, vb.x, vb.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (__ballot(kk[j] != kEmpty && v[j] > 0.0) == 0) continue;           // wave-uniform
+                bool is_sel = false, is_t = false;
+                Cand cd; cd.bits = (u64)__double_as_longlong(v[j]); cd.key = kk[j]; cd.pad = 0;      // (the PACKED key: a merged entry goes back into a table)
+                if (kk[j] != kEmpty && v[j] > 0.0) {
+                    const u32 id = (u32)cd.key & p.node_mask;
+                    const u64 vbits = cd.bits >> vshift;
+                    const bool v_eq = vbits == vpre;
+                    const bool in_bin = v_eq && (ishift >= 32u || (id >> ishift) == ipre);
+                    const bool over = vbits > vpre || (v_eq && ishift < 32u && (id >> ishift) < ipre);
+                    is_sel = over || (in_bin && take_all); is_t = in_bin && !take_all;
+                }
+                const u32 si = wave_alloc1(&ctl->n_sel, is_sel, lane);
+                if (is_sel) t.sel[si] = cd;
+                const u32 ti = wave_alloc1(&ctl->n_tie, is_t, lane);
+                if (is_t) t.tie[ti] = cd;
+            }
+        }
+    }
+    GP_SYNC();
+    sk_rank_selected<BLOCK>(p, ctl, t, need, take_all, my_rank);
     return need;
 }
 
-// TG: coef * share of the row's pushers does not fit LDS beside a useful aggregation table (a hub's thousands of leaves all pushed):
-// the sweep gathers it from HBM instead (L2-hot: 8 bytes per pusher, re-read once per record).
+// TG: coef * share of the row's pushers does not fit LDS beside a useful aggregation table (a hub's thousands of leaves
+// all pushed): the sweep gathers it from HBM instead (L2-hot: 8 bytes per pusher, re-read once per record).
 template <int BLOCK, bool TG>
 __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi, int seed, u32 n_pu, u32 n_log)
 {
@@ -862,7 +895,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
     const u32 K = (u32)p.K;
 
     // T = coef[level] * share of every pusher of the row (graph.h:90 / :109 per edge: what a record adds to its target's reserve).
-    // SCAN left them in HBM with the push-list entries; the level tables are dead and wiped by whoever used them last.
+    // SCAN left them in HBM with the push-list entries; the level sketch's bytes they land in are dead.
     if (!TG) for (u32 i = tid; i < n_pu; i += BLOCK) t.T[i] = w.arch[i];
     for (u32 i = tid; i < 512u; i += BLOCK) t.fine[i] = 0;
     if (tid == 0) { ctl->ovf = 0; ctl->tk_t = 1u; }
@@ -876,28 +909,25 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
         }
     }
     GP_SYNC();
-    if (wave == 0) {                                                                  // lane j owns bins [8 j, 8 j + 8)
-        const SerialSection ahead;
-        u32 cnt[8], sum = 0;
+    u32 t_c;
+    {                                                                                 // every wave reads the histogram itself: lane j owns bins [8 j, 8 j + 8)
+        u32 cnt8[8], sum = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { cnt[j] = t.fine[8 * lane + j]; sum += cnt[j]; }
+        for (int j = 0; j < 8; ++j) { cnt8[j] = t.fine[8 * lane + j]; sum += cnt8[j]; }
         const u32 suf = wave_suffix_scan(sum, lane);                                  // cells in bins >= 8 * lane
         const u64 m = __ballot(suf >= p.sk_target);
+        u32 edge = 1u;
         if (m != 0) {
             const int cl = 63 - __builtin_clzll(m);                                   // highest chunk whose suffix reaches the target
-            if (lane == cl) {
-                u32 acc = suf - sum; int js = 0;
+            u32 acc = suf - sum; int js = 0;
 #pragma unroll
-                for (int j = 7; j >= 0; --j) { acc += cnt[j]; if (acc >= p.sk_target) { js = j; break; } }
-                const u32 bin = 8u * (u32)lane + (u32)js, e = bin >> 4, mt = 16u + (bin & 15u);
-                const u32 edge = e >= 4u ? mt << (e - 4u) : mt >> (4u - e);           // lower edge of the bin (rounded down)
-                ctl->tk_t = max(edge, 1u);
-            }
+            for (int j = 7; j >= 0; --j) { acc += cnt8[j]; if (acc >= p.sk_target) { js = j; break; } }
+            const u32 bin = 8u * (u32)cl + (u32)__builtin_amdgcn_readlane(js, cl), e = bin >> 4, mt = 16u + (bin & 15u);
+            edge = max(e >= 4u ? mt << (e - 4u) : mt >> (4u - e), 1u);                // lower edge of the bin (rounded down)
         }
+        t_c = edge;
     }
-    GP_SYNC();
     SKT(ctl, 7);
-    u32 t_c = uni(ctl->tk_t);
     u32 need = 0, my_rank = 0;
     bool last = false;                                                                // t_c is a proven bound: what this round selects is final
     for (int round = 0; ; ++round) {
@@ -916,7 +946,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
                 GP_SYNC();
                 if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
-                log_groups<BLOCK, true>(w.log_key, w.log_pu, n_log, [&](const int (&k)[4], const u32 (&pu)[4], u32 g0) {
+                log_groups<BLOCK, true>(w.log_key, w.log_pu, 0u, n_log, [&](const int (&k)[4], const u32 (&pu)[4]) {
                     u32 cell[4]; double cv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {                                     // eight lookups in flight
@@ -925,7 +955,6 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (g0 + 64u * (u32)q >= n_log) break;                        // wave-uniform
                         const bool hit = k[q] >= 0 && cv[q] != 0.0 && cell[q] >= t_c;
                         insert_window_asm(t.akeys, t.avals, t.CA, &ctl->ovf, hit ? k[q] : -1, cv[q], P, part);   // graph.h:90 / :109
                     }
@@ -1209,7 +1238,6 @@ __device__ __forceinline__ void gfpush_sk_rows()
     if (tid == 0) { ctl->max_e = 0; ctl->max_log = 0; }
     const long long n_rows = p.n_seeds;
     const u32 L = (u32)p.n_coef - 1u;
-    const u32 top_region = 4u * w.MU + 12u * w.CX;
 
     for (;;) {
         GP_SYNC();
@@ -1237,6 +1265,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
             const u32 n_pu = uni(ctl->tot_pu), n_log = uni(ctl->tot_log);
             if (tid == 0) ctl->max_log = max(ctl->max_log, n_log);
             // (T beside at least half of the aggregation table TOP-K has without it; else the gathering form)
+            const u32 top_region = 4u * w.MU + 12u * w.CX;
             if (2u * sk_top_slots(top_region, n_pu, (u32)p.K) >= sk_top_slots(top_region, 0u, (u32)p.K))
                  phase_sk_topk<BLOCK, false>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, n_pu, n_log);
             else phase_sk_topk<BLOCK, true>(lds0, (u32)(u64)row, (u32)((u64)row >> 32), seed, n_pu, n_log);

@@ -27,7 +27,8 @@ EXPORTS = (
     "gp_graph_device", "gp_gfpush", "gp_gfpush_device", "gp_get_stats", "gp_reset_stats",
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
-    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_graph_acsr",
+    "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_graph_acsr", "gp_graph_create_multi_on",
+    "gp_seed_positions", "gp_batch_positions",
 )
 
 
@@ -88,6 +89,11 @@ def lib():
                                   ctypes.POINTER(vp)]
     L.gp_graph_create_multi.restype = ctypes.c_int
     L.gp_graph_create_multi.argtypes = [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(vp)]
+    try:
+        L.gp_graph_create_multi_on.restype = ctypes.c_int
+        L.gp_graph_create_multi_on.argtypes = [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
+    except AttributeError:                  # (an older build loaded through GRANDPLUS_LIB for an A/B run)
+        pass
     L.gp_graph_num_gpus.restype = ctypes.c_int
     L.gp_graph_num_gpus.argtypes = [vp]
     L.gp_graph_destroy.restype = None
@@ -115,6 +121,13 @@ def lib():
     L.gp_random_prop_coo.restype = ctypes.c_int
     L.gp_random_prop_coo.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, ctypes.c_int64,
                                      ctypes.c_float, ctypes.c_int, ctypes.c_uint64, vp, vp, vp]
+    try:
+        L.gp_seed_positions.restype = ctypes.c_int
+        L.gp_seed_positions.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int64, vp, vp, vp]
+        L.gp_batch_positions.restype = ctypes.c_int
+        L.gp_batch_positions.argtypes = [ctypes.c_int, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, vp]
+    except AttributeError:                  # (an older build loaded through GRANDPLUS_LIB for an A/B run)
+        pass
     L.gp_propagate_features.restype = ctypes.c_int
     L.gp_propagate_features.argtypes = [vp, vp, ctypes.c_int32, vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, vp]
     L.gp_internal_diag_counters.restype = ctypes.c_int

@@ -46,10 +46,12 @@ def _ptr(a, ct):
 class Graph:
     """CSR graph resident in one MI355X's HBM.  Mirrors `propagation.Graph`."""
 
-    def __init__(self, indptr, indices, seed=0, device=None, n_gpus=None):
+    def __init__(self, indptr, indices, seed=0, device=None, n_gpus=None, devices=None):
         """`n_gpus` = None: one GPU (`device`, the form every rank of the torch.distributed driver uses).
         `n_gpus` = 0 / N: a multi-GPU handle over all / the first N visible GPUs (`gp_graph_create_multi`):
-        `gfpush_omp` then shards its seeds over them inside the one call (RCCL all-gather of the rows)."""
+        `gfpush_omp` then shards its seeds over them inside the one call (RCCL all-gather of the rows).
+        `devices` = [0, 0, ...]: such a handle over an explicit device list (`gp_graph_create_multi_on`); a repeated device
+        gives several parts on one GPU, gathered through the host -- the whole sharded path on a one-GPU box."""
         L = _native.lib()
         ip = _as_i32_readonly(indptr, "indptr")
         ix = _as_i32_readonly(indices, "indices")
@@ -62,7 +64,12 @@ class Graph:
             if device >= max(L.gp_device_count(), 1):
                 device = 0
         h = ctypes.c_void_p()
-        if n_gpus is None:
+        if devices is not None:
+            devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            _native.raise_for_status(L.gp_graph_create_multi_on(_ptr(ip, ctypes.c_int32), ip.size - 1, _ptr(ix, ctypes.c_int32), ix.size,
+                                                                devs, len(devices), ctypes.byref(h)))
+            device = L.gp_graph_device(h)
+        elif n_gpus is None:
             _native.raise_for_status(L.gp_graph_create(_ptr(ip, ctypes.c_int32), ip.size - 1,
                                                        _ptr(ix, ctypes.c_int32), ix.size, int(device),
                                                        ctypes.byref(h)))

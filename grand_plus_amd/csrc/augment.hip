@@ -21,6 +21,8 @@
 
 #include "grandplus.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef unsigned long long u64;
@@ -184,9 +186,75 @@ int launch_status(const char* what) {
     return GP_ERR_HIP;
 }
 
+// ---- where is the row of node v?  (`topk_adj[batch_index]`, model.py:310, without the host)
+// pos_of_node[v] = the first position of v in the seed list, -1 for a node that is no seed.
+__global__ void __launch_bounds__(256) seed_positions_init_kernel(int* pos_of_node, long long n_nodes)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += stride) pos_of_node[i] = 0x7FFFFFFF;
+}
+__global__ void __launch_bounds__(256) seed_positions_fill_kernel(const int* seeds, long long n_seeds, int* pos_of_node, long long n_nodes, int* n_bad)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_seeds; i += stride) {
+        const int v = seeds[i];
+        if (v < 0 || v >= n_nodes) { atomicAdd(n_bad, 1); continue; }
+        atomicMin(&pos_of_node[v], (int)i);                           // a duplicated seed keeps its FIRST position
+    }
+}
+__global__ void __launch_bounds__(256) seed_positions_finish_kernel(int* pos_of_node, long long n_nodes)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += stride)
+        if (pos_of_node[i] == 0x7FFFFFFF) pos_of_node[i] = -1;
+}
+__global__ void __launch_bounds__(256) batch_positions_kernel(const int* pos_of_node, long long n_nodes, const long long* node_ids, long long n,
+                                                              int* out, int* n_missing)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long v = node_ids[i];
+        const int pos = v >= 0 && v < n_nodes ? pos_of_node[v] : -1;
+        out[i] = pos;
+        if (pos < 0) atomicAdd(n_missing, 1);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int gp_seed_positions(int device, const int32_t* d_seeds, int64_t n_seeds, int64_t n_nodes, int32_t* d_pos_of_node, int32_t* d_n_bad, void* stream)
+{
+    if (n_nodes < 0 || n_seeds < 0 || n_seeds > 0x7FFFFFFE) { gp_internal_set_error(GP_ERR_INVALID_ARG, "gp_seed_positions", "negative size or more than 2^31 - 2 seeds"); return GP_ERR_INVALID_ARG; }
+    if ((n_nodes > 0 && !d_pos_of_node) || (n_seeds > 0 && !d_seeds) || !d_n_bad) { gp_internal_set_error(GP_ERR_NULL, "gp_seed_positions", "null device pointer"); return GP_ERR_NULL; }
+    if (hipSetDevice(device) != hipSuccess) { gp_internal_set_error(GP_ERR_NO_DEVICE, "gp_seed_positions", "hipSetDevice failed"); return GP_ERR_NO_DEVICE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int grid_n = (int)std::min<int64_t>(4096, (n_nodes + 255) / 256 + 1), grid_s = (int)std::min<int64_t>(4096, (n_seeds + 255) / 256 + 1);
+    if (hipMemsetAsync(d_n_bad, 0, sizeof(int), s) != hipSuccess) { gp_internal_set_error(GP_ERR_HIP, "gp_seed_positions", "hipMemsetAsync failed"); return GP_ERR_HIP; }
+    hipLaunchKernelGGL(seed_positions_init_kernel, dim3(grid_n), dim3(256), 0, s, d_pos_of_node, (long long)n_nodes);
+    hipLaunchKernelGGL(seed_positions_fill_kernel, dim3(grid_s), dim3(256), 0, s, d_seeds, (long long)n_seeds, d_pos_of_node, (long long)n_nodes, d_n_bad);
+    hipLaunchKernelGGL(seed_positions_finish_kernel, dim3(grid_n), dim3(256), 0, s, d_pos_of_node, (long long)n_nodes);
+    if (hipGetLastError() != hipSuccess) { gp_internal_set_error(GP_ERR_HIP, "gp_seed_positions", "kernel launch failed"); return GP_ERR_HIP; }
+    return GP_OK;
+}
+
+int gp_batch_positions(int device, const int32_t* d_pos_of_node, int64_t n_nodes, const int64_t* d_node_ids, int64_t n,
+                       int32_t* d_out, int32_t* d_n_missing, void* stream)
+{
+    if (n < 0 || n_nodes < 0) { gp_internal_set_error(GP_ERR_INVALID_ARG, "gp_batch_positions", "negative size"); return GP_ERR_INVALID_ARG; }
+    if (!d_n_missing || (n > 0 && (!d_pos_of_node || !d_node_ids || !d_out))) { gp_internal_set_error(GP_ERR_NULL, "gp_batch_positions", "null device pointer"); return GP_ERR_NULL; }
+    if (hipSetDevice(device) != hipSuccess) { gp_internal_set_error(GP_ERR_NO_DEVICE, "gp_batch_positions", "hipSetDevice failed"); return GP_ERR_NO_DEVICE; }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(d_n_missing, 0, sizeof(int), s) != hipSuccess) { gp_internal_set_error(GP_ERR_HIP, "gp_batch_positions", "hipMemsetAsync failed"); return GP_ERR_HIP; }
+    if (n > 0) {
+        hipLaunchKernelGGL(batch_positions_kernel, dim3((int)std::min<int64_t>(2048, (n + 255) / 256)), dim3(256), 0, s,
+                           d_pos_of_node, (long long)n_nodes, (const long long*)d_node_ids, (long long)n, d_out, d_n_missing);
+        if (hipGetLastError() != hipSuccess) { gp_internal_set_error(GP_ERR_HIP, "gp_batch_positions", "kernel launch failed"); return GP_ERR_HIP; }
+    }
+    return GP_OK;
+}
+
 
 int gp_random_prop_rows(int device, const float* d_x, int64_t n_nodes, int32_t feat_dim,
                         const int32_t* d_col, const double* d_val, const int32_t* d_filled, int32_t K,

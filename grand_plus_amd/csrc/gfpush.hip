@@ -134,6 +134,7 @@ struct gp_graph {
     // ---- multi-GPU handle (gp_graph_create_multi): this object then owns no device memory itself; part[0] holds the CSR
     //      on the first GPU, the other GPUs get their replica (peer copy) the first time a call is large enough to shard.
     bool multi = false; int n_parts = 0; int force_collective = 0; int gather_host = 0; int64_t min_rows_per_gpu = 2048;
+    bool shared_devices = false;                                          // two parts share a device (gp_graph_create_multi_on): no collective
     std::vector<gp_graph*> part; std::vector<int> devices;
     std::vector<ncclComm_t> comms; bool comms_ready = false;
     std::vector<char*> m_slab, m_gather; std::vector<int*> m_seeds; std::vector<size_t> m_cap_stride; std::vector<int64_t> m_cap_per;
@@ -730,7 +731,10 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     const std::string k(key);
     if (g->multi) {
         if (k == "force_collective") { g->force_collective = value ? 1 : 0; return GP_OK; }
-        if (k == "gather_host") { g->gather_host = value ? 1 : 0; return GP_OK; }
+        if (k == "gather_host") {
+            if (!value && g->shared_devices) return fail(GP_ERR_INVALID_ARG, "parts of this handle share a device: RCCL takes one rank per device, the gather stays on the host");
+            g->gather_host = value ? 1 : 0; return GP_OK;
+        }
         if (k == "min_rows_per_gpu") {
             if (value < 1) return fail(GP_ERR_INVALID_ARG, "min_rows_per_gpu must be >= 1");
             g->min_rows_per_gpu = value; return GP_OK;
@@ -1234,6 +1238,39 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
     return GP_OK;
 }
 
+int gp_graph_create_multi_on(const int32_t* indptr, int64_t n_nodes, const int32_t* indices, int64_t nnz,
+                             const int* devices, int n_parts, gp_graph** out)
+{
+    g_last_error.clear();
+    if (!out) return fail(GP_ERR_NULL, "out is NULL");
+    *out = nullptr;
+    if (!devices || n_parts < 1) return fail(GP_ERR_INVALID_ARG, "gp_graph_create_multi_on needs at least one device");
+    const int ndev = gp_device_count();
+    if (ndev <= 0) return fail(GP_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
+    bool repeated = false;
+    for (int d = 0; d < n_parts; ++d) {
+        if (devices[d] < 0 || devices[d] >= ndev) return fail(GP_ERR_NO_DEVICE, "device %d outside [0, %d)", devices[d], ndev);
+        for (int e = 0; e < d; ++e) repeated |= devices[e] == devices[d];
+    }
+    gp_graph* first = nullptr;
+    int rc = gp_graph_create(indptr, n_nodes, indices, nnz, devices[0], &first);      // validates and uploads once
+    if (rc) return rc;
+    gp_graph* g = new (std::nothrow) gp_graph();
+    if (!g) { gp_graph_destroy(first); return fail(GP_ERR_NOMEM, "host allocation failed"); }
+    g->multi = true; g->n_parts = n_parts; g->n_nodes = n_nodes; g->nnz = nnz;
+    g->part.assign(n_parts, nullptr); g->devices.assign(devices, devices + n_parts);
+    g->part[0] = first;
+    g->comms.assign(n_parts, nullptr);
+    g->m_slab.assign(n_parts, nullptr); g->m_gather.assign(n_parts, nullptr); g->m_seeds.assign(n_parts, nullptr);
+    // several parts on ONE device (a box with a single GPU exercising the whole sharded path): RCCL refuses two ranks per device,
+    // so the slabs come back with one D2H per part ("gather_host"), everything else -- replicas, per-part threads and streams,
+    // seed blocks, the ragged last block, the scatter -- is the code an 8-GPU node runs
+    g->shared_devices = repeated;
+    if (repeated) g->gather_host = 1;
+    *out = g;
+    return GP_OK;
+}
+
 int gp_graph_create_multi(const int32_t* indptr, int64_t n_nodes, const int32_t* indices, int64_t nnz,
                           int n_gpus, gp_graph** out)
 {
@@ -1244,19 +1281,9 @@ int gp_graph_create_multi(const int32_t* indptr, int64_t n_nodes, const int32_t*
     if (ndev <= 0) return fail(GP_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
     if (n_gpus < 0 || n_gpus > ndev) return fail(GP_ERR_NO_DEVICE, "n_gpus = %d but %d device(s) are visible", n_gpus, ndev);
     if (n_gpus == 0) n_gpus = ndev;
-    gp_graph* first = nullptr;
-    int rc = gp_graph_create(indptr, n_nodes, indices, nnz, 0, &first);       // validates and uploads once
-    if (rc) return rc;
-    gp_graph* g = new (std::nothrow) gp_graph();
-    if (!g) { gp_graph_destroy(first); return fail(GP_ERR_NOMEM, "host allocation failed"); }
-    g->multi = true; g->n_parts = n_gpus; g->n_nodes = n_nodes; g->nnz = nnz;
-    g->part.assign(n_gpus, nullptr); g->devices.resize(n_gpus);
-    for (int d = 0; d < n_gpus; ++d) g->devices[d] = d;
-    g->part[0] = first;
-    g->comms.assign(n_gpus, nullptr);
-    g->m_slab.assign(n_gpus, nullptr); g->m_gather.assign(n_gpus, nullptr); g->m_seeds.assign(n_gpus, nullptr);
-    *out = g;
-    return GP_OK;
+    std::vector<int> devs(n_gpus);
+    for (int d = 0; d < n_gpus; ++d) devs[d] = d;
+    return gp_graph_create_multi_on(indptr, n_nodes, indices, nnz, devs.data(), n_gpus, out);
 }
 
 }  // extern "C"
@@ -1289,8 +1316,13 @@ int replicate_part(gp_graph* g, int d) {
     const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));
-    HIP_TRY(hipMemcpyPeer(q->d_indptr, dev, src->d_indptr, src->device, b_ptr));
-    HIP_TRY(hipMemcpyPeer(q->d_indices, dev, src->d_indices, src->device, b_idx));
+    if (dev == src->device) {
+        HIP_TRY(hipMemcpy(q->d_indptr, src->d_indptr, b_ptr, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(q->d_indices, src->d_indices, b_idx, hipMemcpyDeviceToDevice));
+    } else {
+        HIP_TRY(hipMemcpyPeer(q->d_indptr, dev, src->d_indptr, src->device, b_ptr));
+        HIP_TRY(hipMemcpyPeer(q->d_indices, dev, src->d_indices, src->device, b_idx));
+    }
     HIP_TRY(hipMalloc(&q->d_counters, sizeof(u64) * kNumCounters));
     HIP_TRY(hipHostMalloc(&q->h_counters, sizeof(u64) * kNumCounters));
     HIP_TRY(hipEventCreate(&q->ev0));

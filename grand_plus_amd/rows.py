@@ -69,19 +69,45 @@ class RowMatrix:
         return m, False
 
     # ---- hand-off ------------------------------------------------------------------------
-    def batch_positions(self, node_ids):
-        """int32 CUDA tensor of row positions for a batch of node ids (`topk_adj[batch_index]`, model.py:310).
-        Every id must be one of the seeds; for a duplicated seed the first position is used."""
+    def _position_index(self):
+        """int32 CUDA tensor [n_nodes]: first row position of every seed, -1 elsewhere (built on the device, once)."""
+        import ctypes
         import torch
+        from . import _native
         if self._pos is None:
-            self._pos = {}
-            for i, s in enumerate(self.seeds.tolist()):
-                self._pos.setdefault(s, i)
-        try:
-            pos = np.fromiter((self._pos[int(v)] for v in np.asarray(node_ids).reshape(-1)), dtype=np.int32)
-        except KeyError as e:
-            raise KeyError(f"node {e.args[0]} is not among the seeds of this RowMatrix") from None
-        return torch.from_numpy(pos).to(self.col.device)
+            dev = self.col.device
+            seeds = torch.from_numpy(np.ascontiguousarray(self.seeds, dtype=np.int32)).to(dev)
+            pos = torch.empty(self.n_nodes, dtype=torch.int32, device=dev)
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _native.raise_for_status(_native.lib().gp_seed_positions(dev.index, seeds.data_ptr(), seeds.numel(), self.n_nodes,
+                                                                     pos.data_ptr(), bad.data_ptr(), ctypes.c_void_p(stream)))
+            if int(bad.item()):
+                raise ValueError("a seed of this RowMatrix lies outside [0, n_nodes)")
+            self._pos = pos
+        return self._pos
+
+    def batch_positions(self, node_ids, check=True):
+        """int32 CUDA tensor of row positions for a batch of node ids (`topk_adj[batch_index]`, model.py:310): one lookup kernel
+        over a device-resident index, no per-element host work.  `node_ids`: a CUDA / CPU int64 tensor or
+        anything numpy converts.  Every id must be one of the seeds (for a duplicated seed the first position is used): with
+        `check` (one 4-byte D2H) an unknown id raises KeyError, without it its position is -1."""
+        import ctypes
+        import torch
+        from . import _native
+        dev = self.col.device
+        ids = node_ids if isinstance(node_ids, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(node_ids).reshape(-1), dtype=np.int64))
+        ids = ids.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+        pos = self._position_index()
+        out = torch.empty(ids.numel(), dtype=torch.int32, device=dev)
+        missing = torch.zeros(1, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _native.raise_for_status(_native.lib().gp_batch_positions(dev.index, pos.data_ptr(), self.n_nodes, ids.data_ptr(), ids.numel(),
+                                                                  out.data_ptr(), missing.data_ptr(), ctypes.c_void_p(stream)))
+        if check and int(missing.item()):
+            bad = ids[out < 0][0].item()
+            raise KeyError(f"node {bad} is not among the seeds of this RowMatrix")
+        return out
 
     def to_scipy(self):
         """`topk_adj` exactly as the reference builds it (model.py:270-272): a COO over ALL S*K slots -- unfilled

@@ -116,6 +116,13 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes,
 int gp_graph_create_multi(const int32_t* indptr, int64_t n_nodes,
                           const int32_t* indices, int64_t nnz,
                           int n_gpus, gp_graph** out);
+/* The same constructor over an explicit list of devices.  A device may appear more than once: the handle then holds several
+ * parts -- each with its own replica of the CSR, stream, workspace and host thread -- on that one GPU and gathers the slabs
+ * through the host (RCCL takes one rank per device; "gather_host" cannot be switched off on such a handle).  This is how a box
+ * with a single GPU runs the whole sharded path of gp_gfpush; it is not a way to go faster. */
+int gp_graph_create_multi_on(const int32_t* indptr, int64_t n_nodes,
+                             const int32_t* indices, int64_t nnz,
+                             const int* devices, int n_parts, gp_graph** out);
 int gp_graph_num_gpus(const gp_graph* g);
 
 void gp_graph_destroy(gp_graph* g);
@@ -214,6 +221,17 @@ int gp_random_prop_rows(int device, const float* d_x, int64_t n_nodes, int32_t f
                         const int32_t* d_batch_rows, int32_t n_batch,
                         float dropnode_rate, int training, uint64_t seed, const uint8_t* d_keep,
                         float* d_out, void* stream);
+
+/* SURVEY.md 8f next-3 -- where is the row of node v?  The reference slices `topk_adj[batch_index]` on the CPU every step
+ * (model.py:310); here the seed list leaves a device-resident index once per precompute and a batch of node ids is turned into
+ * row positions by one small kernel, no host work per element.
+ * gp_seed_positions: d_pos_of_node int32[n_nodes] <- first position of every seed of d_seeds[n_seeds] (a duplicated seed keeps
+ * its first), -1 for nodes that are no seed; *d_n_bad (device int32) <- seeds outside [0, n_nodes).
+ * gp_batch_positions: d_out[i] <- d_pos_of_node[d_node_ids[i]] (int64 ids, as torch index tensors are), -1 for an id that is no
+ * seed or out of range; *d_n_missing (device int32) <- how many of those.  Both are enqueued on `stream`. */
+int gp_seed_positions(int device, const int32_t* d_seeds, int64_t n_seeds, int64_t n_nodes, int32_t* d_pos_of_node, int32_t* d_n_bad, void* stream);
+int gp_batch_positions(int device, const int32_t* d_pos_of_node, int64_t n_nodes, const int64_t* d_node_ids, int64_t n,
+                       int32_t* d_out, int32_t* d_n_missing, void* stream);
 
 /* Reference-shaped form: feats[n_entries x feat_dim] already gathered, scores[n_entries],
  * idx[n_entries] sorted ascending (the row-major order of scipy's .nonzero(), model.py:312);

@@ -592,6 +592,41 @@ def test_multi_gpu_handle_one_call_uses_every_gpu():
     _assert_parity(seeds, K, single, exp, fill=(-1, -1, -1.0))
 
 
+@pytest.mark.parametrize("n_seeds,devices", [(5000, [0, 0]), (65536 + 1, [0, 0]), (7001, [0, 0, 0])])
+def test_sharded_path_with_several_parts_on_one_device(n_seeds, devices):
+    """The >= 2-part branch of gp_gfpush on the hardware there is: gp_graph_create_multi_on with a repeated device
+    gives the handle several parts on ONE GPU -- replicas (replicate_part), the partition plan, one host thread / stream / workspace
+    per part, seed blocks with a ragged last block, one D2H per part and the scatter of the v > 0 slots -- everything an 8-GPU node
+    runs except the RCCL collective (one rank per device).  Rows and exact counters must equal the single-GPU call's."""
+    from grand_plus_amd import Graph, synth
+    from grand_plus_amd.recipes import RECIPES
+    indptr, indices = synth.shape_csr("small")
+    r = RECIPES[("mag", "ppr")]
+    K = r.top_k
+    n = len(indptr) - 1
+    base = synth.seeds(n, min(n_seeds, n))
+    seeds = np.resize(base, n_seeds)                                   # (more seeds than nodes: duplicates are legal)
+    fill = (-1, -1, -1.0)
+    single, st1 = _run_gpu(indptr, indices, seeds, r.coef(), r.rmax, K, fill=fill)
+    g = Graph(indptr, indices, 0, devices=devices)
+    assert g.n_gpus == len(devices)
+    g.set_option("min_rows_per_gpu", 64)
+    with pytest.raises(ValueError):
+        g.set_option("gather_host", 0)                                 # parts share a device: no collective
+    row = np.full(n_seeds * K, -1, np.int32); col = np.full(n_seeds * K, -1, np.int32); val = np.full(n_seeds * K, -1.0)
+    g.gfpush_omp(seeds, row, col, val, r.coef(), r.rmax, K)
+    st = g.stats()
+    _assert_parity(seeds, K, (row, col, val), single, fill=fill)
+    assert st["rows"] == n_seeds and st["failed_rows"] == 0
+    assert (st["pushes"], st["edges"], st["filled"]) == (st1["pushes"], st1["edges"], st1["filled"])
+    assert st["workgroups"] > st1["workgroups"]                        # every part ran its own launch
+    # a second call on the same handle re-uses replicas and buffers
+    row2 = np.full(n_seeds * K, -1, np.int32); col2 = np.full(n_seeds * K, -1, np.int32); val2 = np.full(n_seeds * K, -1.0)
+    g.gfpush_omp(seeds, row2, col2, val2, r.coef(), r.rmax, K)
+    _assert_parity(seeds, K, (row2, col2, val2), single, fill=fill)
+    g.close()
+
+
 def test_level_one_from_the_seed_row_equals_the_table_path():
     """Level 1 of a row is the seed's neighbour list (graph.h:96-99 applied to level 0's one entry).  On CSRs with strictly
     increasing columns per row the kernel takes it straight from the CSR row (option "seedrow", default on); rows, exact

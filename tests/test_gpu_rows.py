@@ -79,6 +79,32 @@ def test_batch_hand_off_feeds_augmentation():
         m.batch_positions([int(np.setdiff1d(np.arange(n), seeds)[0])])
 
 
+def test_batch_positions_on_the_device_equal_the_dictionary_lookup():
+    """RowMatrix.batch_positions (a device-resident index + one lookup kernel) against the obvious host
+    dictionary {node: first position}: random batches with repeats, duplicated seeds (first position wins), CUDA / CPU / list
+    inputs, an unknown id with and without the check."""
+    import torch
+    from grand_plus_amd.rows import RowMatrix
+    g, indptr, indices, seeds, coef, rmax, K = _setup()
+    seeds = np.concatenate([seeds, seeds[:40][::-1]])                          # duplicates: a later copy must not win
+    m = RowMatrix.compute(g, seeds, coef, rmax, K)
+    ref = {}
+    for i, s_ in enumerate(seeds.tolist()):
+        ref.setdefault(s_, i)
+    rng = np.random.default_rng(3)
+    batch = rng.choice(seeds, size=5000, replace=True)
+    want = np.array([ref[int(v)] for v in batch], np.int32)
+    for form in (batch, batch.tolist(), torch.from_numpy(batch.astype(np.int64)), torch.from_numpy(batch.astype(np.int64)).cuda()):
+        got = m.batch_positions(form)
+        assert got.is_cuda and got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), want)
+    assert m.batch_positions(np.array([], np.int64)).numel() == 0
+    n = len(indptr) - 1
+    stranger = int(np.setdiff1d(np.arange(n), seeds)[0])
+    with pytest.raises(KeyError, match=str(stranger)):
+        m.batch_positions([int(seeds[0]), stranger])
+    assert m.batch_positions([int(seeds[0]), stranger, n + 5, -1], check=False).cpu().tolist() == [ref[int(seeds[0])], -1, -1, -1]
+
+
 def test_precompute_cache(tmp_path):
     """The cached rows are the ORACLE's rows (run_model.py:83-90 recomputes them per run; model.py:251-268), both when
     they were just computed and when they come back from disk."""

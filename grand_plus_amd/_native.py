@@ -48,11 +48,13 @@ class GpStats(ctypes.Structure):
         ("retried_rows", ctypes.c_int64), ("max_level_edges", ctypes.c_int64), ("max_log_records", ctypes.c_int64),
         ("kernel", ctypes.c_int32), ("sketch_pad", ctypes.c_int32),
         ("sketch_candidate_edges", ctypes.c_int64), ("sketch_second_sweeps", ctypes.c_int64),
+        ("choice_ms", ctypes.c_float * 3), ("choice_pad", ctypes.c_int32),
     ]
 
     def as_dict(self):
         d = {name: getattr(self, name) for name, _ in self._fields_}
         d["diag_sub"] = list(self.diag_sub)
+        d["choice_ms"] = list(self.choice_ms)
         return d
 
 
@@ -139,7 +141,7 @@ def lib():
         pass
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
-    if L.gp_abi_version() != 3:
+    if L.gp_abi_version() not in (3, 4):      # (3: an older build loaded through GRANDPLUS_LIB for an A/B run; its gp_stats is a prefix of this one)
         raise RuntimeError("libgrandplus.so ABI version mismatch")
     _LIB = L
     return L

@@ -128,6 +128,13 @@ struct gp_graph {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;                               // used by the host-buffer entry point
     bool launched = false; hipStream_t last_stream = nullptr;
+    // Measured choice: which kernel and launch shape run a recipe on this graph is decided by timing the
+    // candidates -- they are exact and interchangeable -- on the first rows of the first large call of the recipe, not by
+    // thresholds on rmax and graph size.  One entry per (rmax, n_coef, K); ms[] = general kernel in the shape the old
+    // thresholds pick / sketch kernel / general kernel in the other shape (0: not a candidate).
+    struct Choice { double rmax; int n_coef, K; int kernel, block_threads, lds_bytes; float ms[3]; };
+    std::vector<Choice> choices; bool calibrating = false; int measure_choice = 1; u64* d_cal_counters = nullptr;
+    float last_cal_ms[3] = {0.f, 0.f, 0.f};
     bool reset_pending = true; int64_t rows_total = 0;
     gp_stats last{};
     // staging for the host-buffer entry point
@@ -549,6 +556,54 @@ void plan_block(const MultiPlan& m, int d, int64_t n_seeds, int64_t* lo, int64_t
     *n = d < m.G ? std::min<int64_t>(*lo + m.per, n_seeds) - *lo : 0;
 }
 
+constexpr int64_t kCalRows = 2048, kCalMinRows = 4096;      // rows timed per candidate / smallest call that is worth a calibration
+
+// Times the candidates on the first kCalRows rows of the call (into the caller's own output buffers: the call that follows
+// writes the same rows again) and records the fastest as the choice for (rmax, n_coef, K).  Counters of the calibration runs
+// go to a scratch block, the caller's accumulate untouched.  One-off cost: six short launches and two stream synchronisations.
+int calibrate_choice(gp_graph* g, const int32_t* d_seeds, const double* coef, int n_coef, double rmax, int K,
+                     int32_t* d_row, int32_t* d_col, double* d_val, int32_t* d_filled, hipStream_t s)
+{
+    if (!g->d_cal_counters) HIP_TRY(hipMalloc(&g->d_cal_counters, sizeof(u64) * kNumCounters));
+    // the heuristic shape of the general kernel (what gp_gfpush_device picks when nothing is set) and the other one
+    const bool tiny = (double)g->n_nodes <= 0.75 * (double)((80 * 1024 - kCtlBytes) / 12);
+    const bool sparse = g->nnz < 8 * g->n_nodes;
+    const bool two_per_cu = K <= 256 && (tiny || sparse || rmax >= 5e-6);
+    struct Cand { int kernel, block, lds; };
+    const Cand cands[3] = { {1, 0, 0}, {2, 0, 0}, two_per_cu ? Cand{1, 1024, 160 * 1024} : Cand{1, 768, 80 * 1024} };
+    gp_graph::Choice ch; ch.rmax = rmax; ch.n_coef = n_coef; ch.K = K; ch.kernel = 0; ch.block_threads = 0; ch.lds_bytes = 0;
+    ch.ms[0] = ch.ms[1] = ch.ms[2] = 0.f;
+    // (everything the nested calls would change of the caller's statistics is put back afterwards)
+    u64* const counters = g->d_counters; const bool reset_pending = g->reset_pending; const int64_t rows_total = g->rows_total;
+    const gp_stats last = g->last; const bool launched = g->launched;
+    g->d_counters = g->d_cal_counters; g->reset_pending = true;
+    g->calibrating = true;
+    int rc = GP_OK; float best = 0.f;
+    for (int c = 0; c < 3 && rc == GP_OK; ++c) {
+        if (c == 2 && K > 256) continue;                    // (two workgroups per CU need K <= 256: no other shape to try)
+        g->kernel = cands[c].kernel; g->block_threads = cands[c].block; g->lds_bytes = cands[c].lds;
+        float ms = 0.f;
+        for (int rep = 0; rep < 2 && rc == GP_OK; ++rep) {  // (the first run of a kernel pays code upload and first touch of its slabs)
+            g->reset_pending = true;
+            rc = gp_gfpush_device(g, d_seeds, kCalRows, coef, n_coef, rmax, K, d_row, d_col, d_val, d_filled, (void*)s);
+            if (rc) break;
+            if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(GP_ERR_HIP, "calibration: hipStreamSynchronize failed"); break; }
+            if (g->last_kind != cands[c].kernel) { ms = 0.f; break; }          // (the sketch kernel does not take this call: no candidate)
+            if (g->h_counters[kFailedRows]) { ms = 0.f; break; }
+            if (hipEventElapsedTime(&ms, g->ev0, g->ev1) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; break; }
+        }
+        ch.ms[c] = ms;
+        if (ms > 0.f && (best == 0.f || ms < best)) { best = ms; ch.kernel = cands[c].kernel; ch.block_threads = cands[c].block; ch.lds_bytes = cands[c].lds; }
+    }
+    g->kernel = 0; g->block_threads = 0; g->lds_bytes = 0; g->calibrating = false;
+    g->d_counters = counters; g->reset_pending = reset_pending; g->rows_total = rows_total; g->last = last; g->launched = launched;
+    g->grown_for_call = true;                               // (the mirror holds the calibration's counters: nothing to grow from)
+    if (rc) return rc;
+    if (ch.kernel == 0) { ch.kernel = 1; }                  // (nothing could be timed: the general kernel in its heuristic shape)
+    g->choices.push_back(ch);
+    return GP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -710,6 +765,7 @@ void gp_graph_destroy(gp_graph* g) {
     if (g->d_node_pos) (void)hipFree(g->d_node_pos);
     if (g->d_unit_info) (void)hipFree(g->d_unit_info);
     if (g->d_counters) (void)hipFree(g->d_counters);
+    if (g->d_cal_counters) (void)hipFree(g->d_cal_counters);
     if (g->h_counters) (void)hipHostFree(g->h_counters);
     if (g->d_coef) (void)hipFree(g->d_coef);
     if (g->d_seeds) (void)hipFree(g->d_seeds);
@@ -766,6 +822,9 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "sk_target") {
         if (value < 0 || value > 4096) return fail(GP_ERR_INVALID_ARG, "sk_target must be in [0, 4096]");
         g->sk_target = (int)value;
+    } else if (k == "measure_choice") {
+        g->measure_choice = value ? 1 : 0;       // 0 = kernel and launch shape from the rmax / graph-size thresholds alone (what calls below 4 096 rows always get)
+        if (!value) g->choices.clear();
     } else if (k == "pretouch") {
         g->pretouch = value ? 1 : 0;             // memset the whole workspace when it is allocated (slow-phase experiment)
     } else if (k == "max_workgroups") {
@@ -811,6 +870,27 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     if (n_seeds > 0 && (!d_seeds || !d_row || !d_col || !d_val)) return fail(GP_ERR_NULL, "a device buffer is NULL");
     HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = (hipStream_t)stream;
+#ifndef GP_DIAG
+    if (g->kernel == 0 && g->block_threads == 0 && g->lds_bytes == 0 && g->measure_choice && !g->calibrating &&
+        !g->force_global && !g->exact_stats && n_seeds >= kCalMinRows) {
+        gp_graph::Choice* c = nullptr;
+        for (auto& e : g->choices) if (e.rmax == rmax && e.n_coef == n_coef && e.K == K) c = &e;
+        if (!c) {
+            rc = calibrate_choice(g, d_seeds, coef, n_coef, rmax, K, d_row, d_col, d_val, d_filled, s);
+            if (rc) return rc;
+            c = &g->choices.back();
+        }
+        // the call itself, with the measured kernel and shape as if the caller had set them
+        g->calibrating = true;
+        g->kernel = c->kernel; g->block_threads = c->block_threads; g->lds_bytes = c->lds_bytes;
+        rc = gp_gfpush_device(g, d_seeds, n_seeds, coef, n_coef, rmax, K, d_row, d_col, d_val, d_filled, stream);
+        g->kernel = 0; g->block_threads = 0; g->lds_bytes = 0;
+        g->calibrating = false;
+        std::memcpy(g->last_cal_ms, c->ms, sizeof g->last_cal_ms);
+        return rc;
+    }
+    if (!g->calibrating) std::memset(g->last_cal_ms, 0, sizeof g->last_cal_ms);
+#endif
     // workspace and counters are per graph: launches on one stream are ordered by the stream,
     // a launch on a DIFFERENT stream first waits for the previous one
     if (g->launched && g->last_stream != s) HIP_TRY(hipStreamSynchronize(g->last_stream));
@@ -1112,6 +1192,7 @@ int gp_get_stats(gp_graph* g, gp_stats* out) {
     s.max_log_records = (int64_t)g->h_counters[kMaxLogRecords];
     s.sketch_candidate_edges = (int64_t)g->h_counters[kSkCandEdges];
     s.sketch_second_sweeps = (int64_t)g->h_counters[kSkSweep2];
+    for (int i = 0; i < 3; ++i) s.choice_ms[i] = g->last_cal_ms[i];
     grow_estimate(g);                           // (the call has completed: size the next one's slabs from its retry rate)
     s.diag_ticks_scan = (int64_t)g->h_counters[kTicksScan];
     s.diag_ticks_expand = (int64_t)g->h_counters[kTicksExpand];

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"libgrandplus.so does not export {name}"
-    assert _native.lib().gp_abi_version() == 3
+    assert _native.lib().gp_abi_version() == 4
     assert _native.lib().gp_strerror(2) == b"invalid CSR"
 
 
@@ -35,7 +35,7 @@ def test_stats_struct_matches_header():
     body = text[text.index("typedef struct gp_stats {"):text.index("} gp_stats;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
-    for decl in re.findall(r"(?:int64_t|int32_t|double)\s+([^;]+);", body):
+    for decl in re.findall(r"(?:int64_t|int32_t|double|float)\s+([^;]+);", body):
         for item in decl.split(","):
             names.append(re.sub(r"\[.*\]", "", item).strip())
     assert names == [n for n, _ in _native.GpStats._fields_]

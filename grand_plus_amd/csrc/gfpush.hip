@@ -556,7 +556,11 @@ void plan_block(const MultiPlan& m, int d, int64_t n_seeds, int64_t* lo, int64_t
     *n = d < m.G ? std::min<int64_t>(*lo + m.per, n_seeds) - *lo : 0;
 }
 
-constexpr int64_t kCalRows = 2048, kCalMinRows = 4096;      // rows timed per candidate / smallest call that is worth a calibration
+// Rows timed per candidate / smallest call that is worth a calibration.  16 384 rows are ~30 rows per resident workgroup: both
+// kernels LEARN per workgroup how to plan a level (cand_q / ratio_q) and pay for an overflowed pass while they do; on 2 048 rows
+// (4 per workgroup) the MAG line's sketch kernel timed 2.0 ms against 1.4 ms for the general kernel in its slowest shape, which
+// takes 36 ms against 21 ms on a full call.
+constexpr int64_t kCalRows = 16384, kCalMinRows = 32768;
 
 // Times the candidates on the first kCalRows rows of the call (into the caller's own output buffers: the call that follows
 // writes the same rows again) and records the fastest as the choice for (rmax, n_coef, K).  Counters of the calibration runs
@@ -578,7 +582,7 @@ int calibrate_choice(gp_graph* g, const int32_t* d_seeds, const double* coef, in
     const gp_stats last = g->last; const bool launched = g->launched;
     g->d_counters = g->d_cal_counters; g->reset_pending = true;
     g->calibrating = true;
-    int rc = GP_OK; float best = 0.f;
+    int rc = GP_OK; float best = 0.f; (void)best;
     for (int c = 0; c < 3 && rc == GP_OK; ++c) {
         if (c == 2 && K > 256) continue;                    // (two workgroups per CU need K <= 256: no other shape to try)
         g->kernel = cands[c].kernel; g->block_threads = cands[c].block; g->lds_bytes = cands[c].lds;
@@ -593,7 +597,13 @@ int calibrate_choice(gp_graph* g, const int32_t* d_seeds, const double* coef, in
             if (hipEventElapsedTime(&ms, g->ev0, g->ev1) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; break; }
         }
         ch.ms[c] = ms;
-        if (ms > 0.f && (best == 0.f || ms < best)) { best = ms; ch.kernel = cands[c].kernel; ch.block_threads = cands[c].block; ch.lds_bytes = cands[c].lds; }
+    }
+    {   // what the thresholds would pick stays unless another candidate is more than 5 % faster (timing noise must not flip a recipe)
+        const int heur = rmax >= 5e-6 && g->n_nodes >= 65536 && ch.ms[1] > 0.f ? 1 : 0;
+        int pick = ch.ms[heur] > 0.f ? heur : -1;
+        for (int c = 0; c < 3; ++c)
+            if (ch.ms[c] > 0.f && (pick < 0 || ch.ms[c] < 0.95f * ch.ms[pick])) pick = c;
+        if (pick >= 0) { best = ch.ms[pick]; ch.kernel = cands[pick].kernel; ch.block_threads = cands[pick].block; ch.lds_bytes = cands[pick].lds; }
     }
     g->kernel = 0; g->block_threads = 0; g->lds_bytes = 0; g->calibrating = false;
     g->d_counters = counters; g->reset_pending = reset_pending; g->rows_total = rows_total; g->last = last; g->launched = launched;

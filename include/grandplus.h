@@ -79,9 +79,10 @@ typedef struct gp_stats {
     int64_t sketch_candidate_edges;  /* pushed edges whose target might push and went into the exact table (of `edges`) */
     int64_t sketch_second_sweeps;    /* rows whose top-K needed a second sweep over their log                          */
     /* ABI 4: the measured choice.  With nothing forced (options kernel / block_threads / lds_bytes all 0, "measure_choice" 1) the
-     * first call of >= 4 096 rows of a recipe (rmax, n_coef, K) on a graph times its candidates -- they are exact and
-     * interchangeable -- on its first 2 048 rows and every later call of that recipe runs the fastest: [0] the general kernel in
-     * the launch shape the rmax / graph-size thresholds pick, [1] the sketch kernel, [2] the general kernel in the other shape.
+     * first call of >= 32 768 rows of a recipe (rmax, n_coef, K) on a graph times its candidates -- they are exact and
+     * interchangeable -- on its first 16 384 rows, and every later call of that recipe runs what the rmax / graph-size thresholds
+     * pick unless another candidate was more than 5 % faster: [0] the general kernel in the launch shape the thresholds pick,
+     * [1] the sketch kernel, [2] the general kernel in the other shape.
      * Milliseconds of those timing runs behind the LAST call's decision (0 = not a candidate / nothing was measured for it);
      * `kernel`, `block_threads`, `lds_bytes` say what ran. */
     float   choice_ms[3];

@@ -13,21 +13,29 @@ a = ap.parse_args()
 per = {}; n_avg = {}; kernels = set()
 for f in sorted(glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True)):
     by = defaultdict(lambda: defaultdict(float))          # counter -> dispatch -> value
+    first = {}                                            # dispatch -> does it start a call (the kernel that takes every row)
     for r in csv.DictReader(open(f)):
         if "gfpush_" not in r["Kernel_Name"] or "kernel<" not in r["Kernel_Name"]:
             continue
         kernels.add(r["Kernel_Name"].split("(")[0])
-        by[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
-    for c, d in by.items():
-        vals = [d[k] for k in sorted(d)]
-        calls = a.warmup + a.steps
-        if len(vals) % calls:
-            print(f"{c}: {len(vals)} gfpush launches are not a multiple of {calls} calls -- skipped", file=sys.stderr)
-            continue
-        lpc = len(vals) // calls                          # launches per call
-        timed = vals[a.warmup * lpc:]
-        per[c] = sum(timed) / a.steps
-        n_avg[c] = {"calls": a.steps, "launches_per_call": lpc}
+        d = int(r["Dispatch_Id"])
+        by[r["Counter_Name"]][d] += float(r["Counter_Value"])
+        first[d] = "gfpush_retry_kernel" not in r["Kernel_Name"]
+    # a call = one launch of gfpush_kernel / gfpush_sk_kernel and the retry launches behind it; the timed calls are the LAST
+    # `steps` calls of the process (in front of them: warm-up calls and, once per recipe, the short launches that time the
+    # candidates of the measured choice)
+    order = sorted(first)
+    calls = []
+    for d in order:
+        if first[d]: calls.append([d])
+        elif calls: calls[-1].append(d)
+    if len(calls) < a.steps:
+        print(f"{f}: {len(calls)} gfpush calls, fewer than the {a.steps} timed steps -- skipped", file=sys.stderr)
+        continue
+    timed = calls[-a.steps:]
+    for c, dd in by.items():
+        per[c] = sum(dd[d] for call in timed for d in call) / a.steps
+        n_avg[c] = {"calls": a.steps, "launches_per_call": len(timed[-1]), "calls_in_process": len(calls)}
 g = per.get
 d = {}
 if g("TCC_EA0_RDREQ_sum"): d["hbm_read_bytes_raw"] = g("TCC_EA0_RDREQ_sum") * 64

@@ -608,6 +608,7 @@ int calibrate_choice(gp_graph* g, const int32_t* d_seeds, const double* coef, in
     g->kernel = 0; g->block_threads = 0; g->lds_bytes = 0; g->calibrating = false;
     g->d_counters = counters; g->reset_pending = reset_pending; g->rows_total = rows_total; g->last = last; g->launched = launched;
     g->grown_for_call = true;                               // (the mirror holds the calibration's counters: nothing to grow from)
+    free_workspace(g->ws);                                  // (it holds slabs for every candidate: the calls that follow allocate what the chosen one needs)
     if (rc) return rc;
     if (ch.kernel == 0) { ch.kernel = 1; }                  // (nothing could be timed: the general kernel in its heuristic shape)
     g->choices.push_back(ch);

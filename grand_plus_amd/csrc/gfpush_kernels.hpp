@@ -538,6 +538,136 @@ __device__ __forceinline__ void insert_window_asm(int* keys, double* vals, u32 c
         : "vcc", "scc", "memory");
 }
 
+// FOUR windows inserted together (round 5).  insert_window_asm called four times is four DEPENDENT LDS round trips -- compare-and-swap,
+// wait, add, next window -- and the steps of EXPAND / STREAM / FILTER / the TOP-K sweep are chains of exactly those.  Here the four
+// windows' home slots are computed side by side, their four compare-and-swaps are issued back to back (the LDS executes a wave's
+// operations in order, so two windows that hold the same key see each other: the second finds the first one's claim), and only the
+// lanes whose home slot belonged to another key (~ a quarter at half load) walk on, window by window, in the loop of
+// insert_window_asm.  One round trip per step instead of four.  (Waits: when window q is resolved, the compare-and-swaps of the
+// windows behind it are younger than its own -- lgkmcnt(3 - q) says it has returned, however many adds were issued in between.)
+#define GP_IW4_EACH(X) X(0) X(1) X(2) X(3)
+#define GP_IW4_MASK(q)   "v_cmp_lt_i32_e64 %[m" #q "], -1, %[c" #q "]\n\t"                       /* lanes that hold an edge */
+#define GP_IW4_F1(q)     "v_mul_lo_u32 %[se" #q "], %[c" #q "], %[st]\n\t"                        /* hash_b -> partition */
+#define GP_IW4_F2(q)     "v_lshrrev_b32 %[sl" #q "], 16, %[se" #q "]\n\t" "v_xor_b32 %[se" #q "], %[sl" #q "], %[se" #q "]\n\t"
+#define GP_IW4_F3(q)     "v_mul_lo_u32 %[se" #q "], %[se" #q "], %[st]\n\t"
+#define GP_IW4_F4(q)     "v_mul_hi_u32 %[se" #q "], %[se" #q "], %[parts]\n\t"
+#define GP_IW4_F5(q)     "v_cmp_eq_u32_e64 vcc, %[part], %[se" #q "]\n\t" "s_and_b64 %[m" #q "], %[m" #q "], vcc\n\t"
+#define GP_IW4_H1(q)     "v_mul_lo_u32 %[sl" #q "], %[c" #q "], %[st]\n\t"                        /* hash_a -> home slot */
+#define GP_IW4_H2(q)     "v_lshrrev_b32 %[se" #q "], 15, %[sl" #q "]\n\t" "v_xor_b32 %[sl" #q "], %[se" #q "], %[sl" #q "]\n\t"
+#define GP_IW4_H3(q)     "v_mul_lo_u32 %[sl" #q "], %[sl" #q "], %[st]\n\t"
+#define GP_IW4_H4(q)     "v_mul_hi_u32 %[sl" #q "], %[sl" #q "], %[capm]\n\t" "v_lshl_add_u32 %[se" #q "], %[sl" #q "], 2, %[kb]\n\t"
+#define GP_IW4_HASHES \
+        "s_mov_b32 %[st], 0x9e3779b1\n\t" GP_IW4_EACH(GP_IW4_H1) GP_IW4_EACH(GP_IW4_H2) \
+        "s_mov_b32 %[st], 0x85ebca77\n\t" GP_IW4_EACH(GP_IW4_H3) GP_IW4_EACH(GP_IW4_H4)
+#define GP_IW4_WALK(q) \
+        "v_cmpx_ne_u32 vcc, %[se" #q "], %[c" #q "]\n\t" \
+        "v_cmpx_ne_u32 vcc, -1, %[se" #q "]\n\t" \
+        "s_cbranch_execz 3" #q "f\n\t" \
+        "s_mov_b32 %[st], 1\n" \
+        "1" #q ":\n\t" \
+        "v_add_u32 %[sl" #q "], %[st], %[sl" #q "]\n\t" \
+        "s_add_u32 %[st], %[st], 1\n\t" \
+        "s_cmp_le_u32 %[st], %[lim]\n\t" \
+        "s_cbranch_scc0 2" #q "f\n\t" \
+        "v_lshl_add_u32 %[se" #q "], %[sl" #q "], 2, %[kb]\n\t" \
+        "ds_cmpst_rtn_b32 %[se" #q "], %[se" #q "], %[emp], %[c" #q "]\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_cmpx_ne_u32 vcc, %[se" #q "], %[c" #q "]\n\t" \
+        "v_cmpx_ne_u32 vcc, -1, %[se" #q "]\n\t" \
+        "s_cbranch_execnz 1" #q "b\n\t" \
+        "s_branch 3" #q "f\n" \
+        "2" #q ":\n\t" \
+        "v_mov_b32 %[sl" #q "], 1\n\t"                            /* probe limit reached: the lanes still searching give up (their slot is not used again) */ \
+        "v_mov_b32 %[se" #q "], %[fa]\n\t" \
+        "ds_write_b32 %[se" #q "], %[sl" #q "]\n" \
+        "3" #q ":\n\t"
+// (with a partition filter: the four lane masks live in scalar registers)
+#define GP_IW4_ISSUE_M(q) \
+        "s_mov_b64 exec, %[m" #q "]\n\t" \
+        "ds_cmpst_rtn_b32 %[se" #q "], %[se" #q "], %[emp], %[c" #q "]\n\t"
+#define GP_IW4_RESOLVE_M(q, cnt) \
+        "s_waitcnt lgkmcnt(" #cnt ")\n\t" \
+        "s_mov_b64 exec, %[m" #q "]\n\t" \
+        GP_IW4_WALK(q) \
+        "s_andn2_b64 exec, %[m" #q "], exec\n\t"                  /* the lanes that found or claimed their slot */ \
+        "v_lshl_add_u32 %[se" #q "], %[sl" #q "], 3, %[vb]\n\t" \
+        "ds_add_f64 %[se" #q "], %[s" #q "]\n\t"
+// (without: a window's mask is one compare away -- no scalar registers are held for it)
+#define GP_IW4_ISSUE_C(q) \
+        "v_cmpx_lt_i32 vcc, -1, %[c" #q "]\n\t" \
+        "ds_cmpst_rtn_b32 %[se" #q "], %[se" #q "], %[emp], %[c" #q "]\n\t" \
+        "s_mov_b64 exec, %[sv]\n\t"
+#define GP_IW4_RESOLVE_C(q, cnt) \
+        "s_waitcnt lgkmcnt(" #cnt ")\n\t" \
+        "v_cmpx_lt_i32 vcc, -1, %[c" #q "]\n\t" \
+        "s_mov_b64 %[ent], exec\n\t" \
+        GP_IW4_WALK(q) \
+        "s_andn2_b64 exec, %[ent], exec\n\t" \
+        "v_lshl_add_u32 %[se" #q "], %[sl" #q "], 3, %[vb]\n\t" \
+        "ds_add_f64 %[se" #q "], %[s" #q "]\n\t" \
+        "s_mov_b64 exec, %[sv]\n\t"
+template <bool PART>
+__device__ __forceinline__ void insert_windows4_asm(int* keys, double* vals, u32 cap, u32* flag, const int (&col)[4], const double (&sh)[4],
+                                                    u32 parts, u32 part)
+{
+    u32 sl0, sl1, sl2, sl3, se0, se1, se2, se3, st; u64 sv;
+    if (PART) {
+        u64 m0, m1, m2, m3;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            GP_IW4_EACH(GP_IW4_MASK)
+            "s_cmp_eq_u32 %[parts], 1\n\t"
+            "s_cbranch_scc1 4f\n\t"
+            "s_mov_b32 %[st], 0x7feb352d\n\t" GP_IW4_EACH(GP_IW4_F1) GP_IW4_EACH(GP_IW4_F2)
+            "s_mov_b32 %[st], 0x846ca68b\n\t" GP_IW4_EACH(GP_IW4_F3) GP_IW4_EACH(GP_IW4_F4) GP_IW4_EACH(GP_IW4_F5)
+            "4:\n\t"
+            GP_IW4_HASHES
+            GP_IW4_EACH(GP_IW4_ISSUE_M)
+            GP_IW4_RESOLVE_M(0, 3) GP_IW4_RESOLVE_M(1, 2) GP_IW4_RESOLVE_M(2, 1) GP_IW4_RESOLVE_M(3, 0)
+            "s_mov_b64 exec, %[sv]"
+            : [sl0] "=&v"(sl0), [sl1] "=&v"(sl1), [sl2] "=&v"(sl2), [sl3] "=&v"(sl3),
+              [se0] "=&v"(se0), [se1] "=&v"(se1), [se2] "=&v"(se2), [se3] "=&v"(se3),
+              [sv] "=&s"(sv), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [st] "=&s"(st)
+            : [c0] "v"(col[0]), [c1] "v"(col[1]), [c2] "v"(col[2]), [c3] "v"(col[3]), [s0] "v"(sh[0]), [s1] "v"(sh[1]), [s2] "v"(sh[2]), [s3] "v"(sh[3]),
+              [emp] "v"(kEmpty), [parts] "s"(parts), [part] "s"(part),
+              [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
+            : "vcc", "scc", "memory");
+    } else {
+        u64 ent;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            GP_IW4_HASHES
+            GP_IW4_EACH(GP_IW4_ISSUE_C)
+            GP_IW4_RESOLVE_C(0, 3) GP_IW4_RESOLVE_C(1, 2) GP_IW4_RESOLVE_C(2, 1) GP_IW4_RESOLVE_C(3, 0)
+            : [sl0] "=&v"(sl0), [sl1] "=&v"(sl1), [sl2] "=&v"(sl2), [sl3] "=&v"(sl3),
+              [se0] "=&v"(se0), [se1] "=&v"(se1), [se2] "=&v"(se2), [se3] "=&v"(se3),
+              [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
+            : [c0] "v"(col[0]), [c1] "v"(col[1]), [c2] "v"(col[2]), [c3] "v"(col[3]), [s0] "v"(sh[0]), [s1] "v"(sh[1]), [s2] "v"(sh[2]), [s3] "v"(sh[3]),
+              [emp] "v"(kEmpty),
+              [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
+            : "vcc", "scc", "memory");
+    }
+}
+
+
+// Two windows together, no partition filter: for the step loops that have no registers to spare (a small level's STREAM holds its
+// whole enumeration state beside the insert; two more live registers there are three callee-saved ones saved to scratch per call).
+#define GP_IW2_EACH(X) X(0) X(1)
+__device__ __forceinline__ void insert_windows2_asm(int* keys, double* vals, u32 cap, u32* flag, int c0, int c1, double s0, double s1)
+{
+    u32 sl0, sl1, se0, se1, st; u64 sv, ent;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[st], 0x9e3779b1\n\t" GP_IW2_EACH(GP_IW4_H1) GP_IW2_EACH(GP_IW4_H2)
+        "s_mov_b32 %[st], 0x85ebca77\n\t" GP_IW2_EACH(GP_IW4_H3) GP_IW2_EACH(GP_IW4_H4)
+        GP_IW2_EACH(GP_IW4_ISSUE_C)
+        GP_IW4_RESOLVE_C(0, 1) GP_IW4_RESOLVE_C(1, 0)
+        : [sl0] "=&v"(sl0), [sl1] "=&v"(sl1), [se0] "=&v"(se0), [se1] "=&v"(se1), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
+        : [c0] "v"(c0), [c1] "v"(c1), [s0] "v"(s0), [s1] "v"(s1), [emp] "v"(kEmpty),
+          [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
+}
+
 // A serial step of a workgroup -- one wave works, the others wait for it at a barrier: that wave goes ahead of the CU's other
 // workgroup at instruction issue for as long as this object lives (s_setprio; measured on the MAG line: -0.6 % kernel time).
 struct SerialSection {

@@ -56,6 +56,9 @@
 
 namespace gp {
 
+#ifndef GP_SK_SWEEP_DEPTH
+#define GP_SK_SWEEP_DEPTH 2               // groups of log records in flight per wave in TOP-K's sweep
+#endif
 constexpr int kSkMaxCoef = 40;            // levels the control block has room for (longer recipes: general kernel)
 constexpr u32 kSkTie     = 256;           // the select ranks at most this many candidates by comparison
 constexpr u32 kSkMulA    = 0x9E3779B1u;   // sketch hash: cell = top bits of key * kSkMulA
@@ -191,6 +194,51 @@ __device__ __forceinline__ void log_groups(const int* lk, const unsigned short* 
         if (more) load(g);
         f(k, pu);
         if (!more) break;
+    }
+}
+
+// The same walk with TWO groups' loads in flight (TOP-K's sweep: ~9 groups per wave of records that left the L2 long ago, so a
+// group's loads take an HBM / Infinity-Cache round trip and one group ahead does not cover it).  The loop is unrolled by two so
+// that the two register sets alternate without moves.
+template <int BLOCK, class F>
+__device__ __forceinline__ void log_groups2_nt(const int* lk, const unsigned short* lp, u32 end, F f)
+{
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef u32 u2 __attribute__((ext_vector_type(2)));
+    constexpr u32 kStride = (BLOCK / 64) * 256u;
+    const u32 lane = threadIdx.x & 63u;
+    u32 g = wave_id() * 256u;
+    if (g >= end) return;
+    const u32 last_chunk = (end - 1u) & ~3u;
+    i4 ka, kb; u2 pa, pb;
+    auto load = [&](u32 g0, i4& kn, u2& pn) {
+        const u32 i = min(g0 + 4u * lane, last_chunk);
+        kn = __builtin_nontemporal_load((const i4*)&lk[i]); pn = __builtin_nontemporal_load((const u2*)&lp[i]);
+    };
+    auto consume = [&](u32 g0, const i4& kn, const u2& pn, int (&k)[4], u32 (&pu)[4]) {
+        const u32 i0 = g0 + 4u * lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = i0 + (u32)q < end;
+            k[q] = in ? kn[q] : -1;
+            pu[q] = in ? (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu : 0u;
+        }
+    };
+    load(g, ka, pa);
+    kb = ka; pb = pa;
+    if (g + kStride < end) load(g + kStride, kb, pb);
+    for (;;) {
+        int k[4]; u32 pu[4];
+        consume(g, ka, pa, k, pu);
+        if (g + 2u * kStride < end) load(g + 2u * kStride, ka, pa);      // (wave-uniform)
+        f(k, pu);
+        g += kStride;
+        if (g >= end) break;
+        consume(g, kb, pb, k, pu);
+        if (g + 2u * kStride < end) load(g + 2u * kStride, kb, pb);
+        f(k, pu);
+        g += kStride;
+        if (g >= end) break;
     }
 }
 
@@ -406,9 +454,12 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
                 if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(sh[q] * cs));       // graph.h:90 / :109, as an upper bound
                 if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(sh[q] * 2147483648.0));
             }
-            if (MODE == 1) insert_window_all_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q]);
-            if (MODE == 3) insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[q], sh[q], parts, part);
         }
+        if (MODE == 1) {                                                                  // graph.h:98, two windows' compare-and-swaps in flight together
+            insert_windows2_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[0], v[1], sh[0], sh[1]);
+            insert_windows2_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, v[2], v[3], sh[2], sh[3]);
+        }
+        if (MODE == 3) insert_windows4_asm<true>(w.xkeys, w.xvals, capx, &w.ctl->ovf, v, sh, parts, part);
     });
     if (threadIdx.x == 0 && w.ctl->lv_has_dang) {                                     // graph.h:92: the seed gets the dangling mass
         const double dang = w.ctl->lv_dang; const int seed_key = w.ctl->seed_key;
@@ -444,6 +495,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
             cell[q] = w.U[((u32)max(k[q], 0) * kSkMulA) >> w.shU];
             s[q] = S[k[q] >= 0 ? pu[q] - pu_base : 0u];
         }
+        int kc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bool cand = k[q] >= 0;
@@ -452,8 +504,9 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
                 cand = (float)cell[q] >= (float)dq * thr;                             // thr = rmax * 2^31 * (1 - 2^-10), rounded down
             }
             n_cand += (u32)__popcll(__ballot(cand));
-            insert_window_asm(w.xkeys, w.xvals, capx, &w.ctl->ovf, cand ? k[q] : -1, s[q], parts, part);   // graph.h:98
+            kc[q] = cand ? k[q] : -1;
         }
+        insert_windows4_asm<true>(w.xkeys, w.xvals, capx, &w.ctl->ovf, kc, s, parts, part);     // graph.h:98
     });
     if ((threadIdx.x & 63u) == 0 && n_cand && part == 0u) zstat(w.ctl, zCand, n_cand);
     SKT2(w.ctl, 1);
@@ -946,19 +999,23 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
                 GP_SYNC();
                 if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
-                log_groups<BLOCK, true>(w.log_key, w.log_pu, 0u, n_log, [&](const int (&k)[4], const u32 (&pu)[4]) {
+                auto tabled = [&](const int (&k)[4], const u32 (&pu)[4]) {
                     u32 cell[4]; double cv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {                                     // eight lookups in flight
                         cell[q] = t.R[((u32)max(k[q], 0) * kSkMulA) >> t.shR];
                         cv[q] = TG ? w.arch[pu[q]] : t.T[pu[q]];
                     }
+                    int kh[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool hit = k[q] >= 0 && cv[q] != 0.0 && cell[q] >= t_c;
-                        insert_window_asm(t.akeys, t.avals, t.CA, &ctl->ovf, hit ? k[q] : -1, cv[q], P, part);   // graph.h:90 / :109
-                    }
-                });
+                    for (int q = 0; q < 4; ++q) kh[q] = k[q] >= 0 && cv[q] != 0.0 && cell[q] >= t_c ? k[q] : -1;
+                    insert_windows4_asm<true>(t.akeys, t.avals, t.CA, &ctl->ovf, kh, cv, P, part);               // graph.h:90 / :109
+                };
+#if GP_SK_SWEEP_DEPTH == 2
+                log_groups2_nt<BLOCK>(w.log_key, w.log_pu, n_log, tabled);
+#else
+                log_groups<BLOCK, true>(w.log_key, w.log_pu, 0u, n_log, tabled);
+#endif
                 GP_SYNC();
                 SKT(ctl, 8);
                 if (uni(ctl->ovf)) { ovf = true; break; }

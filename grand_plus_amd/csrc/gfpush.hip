@@ -233,7 +233,7 @@ Slabs slab_sizes(const gp_graph* g, int n_coef, double e_max, double log_records
 // The sketch kernel's slab: two push lists, two boundary tables and the per-EDGE reserve log (`log_records` = edges of a row).
 Slabs sk_slab_sizes(const gp_graph* g, double e_max, double log_records, bool at_bound) {
     Slabs sl;
-    sl.log_cap = ((u64)(log_records + 64.0) + 3) & ~3ull;
+    sl.log_cap = ((u64)std::min(log_records + 64.0, 4.0e9) + 3) & ~3ull;     // (log positions are 32-bit words in the kernel: a row with more records outgrows its slab and is retried)
     // one entry per pushing node: a few per cent of a level's edges on the graphs the estimate is for (a level with more: general
     // kernel); every node of the level when the slabs are sized from the bound anyway (small graphs)
     sl.push_cap = (u64)(std::min((double)g->n_nodes, at_bound ? e_max : std::max(e_max / 4.0, 4096.0)) + 2.0);

@@ -117,6 +117,9 @@ struct SkView {
     u32 lds_u;                            // byte offset of U inside LDS
     u32* bt_l; u32 bt_l_cap;              // the head of the current boundary table, in the flag bytes no wave of this block size owns
 };
+// (BLOCK is a template argument, not blockDim.x: the latter is a 16-bit word of the hidden kernel arguments that only a VECTOR load
+//  reads -- one global round trip at the top of every phase that asked for it.)
+template <int BLOCK>
 __device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
     SkView w;
     w.MU = 1u << p.sk_lg_mu; w.MR = 1u << p.sk_lg_mr; w.CX = p.sk_cx;
@@ -127,14 +130,16 @@ __device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
     w.U = lds_at<u32>(w.lds_u);
     w.xvals = lds_at<double>(w.lds_u + 4u * w.MU);
     w.xkeys = lds_at<int>(w.lds_u + 4u * w.MU + 8u * w.CX);
-    w.bt_l = lds_at<u32>(lds0 + (u32)kCtlStruct + 64u * kFlatW * (blockDim.x >> 6));
-    w.bt_l_cap = 16u * kFlatW * (16u - (blockDim.x >> 6));      // 256 words at 768 threads (levels of <= 16 Ki edges), 512 at 512
-    const size_t wg = blockIdx.x;
-    w.push2   = p.push + wg * 2 * p.push_cap;
-    w.bt2     = p.bt + wg * 2 * p.bt_cap;
-    w.log_key = p.log_key + wg * p.log_cap;
-    w.log_pu  = p.log_pu + wg * p.log_cap;
-    w.arch    = p.arch + wg * p.arch_cap;
+    w.bt_l = lds_at<u32>(lds0 + (u32)kCtlStruct + 64u * kFlatW * (u32)(BLOCK / 64));
+    w.bt_l_cap = 16u * kFlatW * (16u - (u32)(BLOCK / 64));      // 256 words at 768 threads (levels of <= 16 Ki edges), 512 at 512
+    // (this kernel's slab capacities are below 2^32 records -- gfpush.hip:sk_slab_sizes --: one 32 x 32 -> 64-bit scalar multiply each)
+    const u32 wg = blockIdx.x;
+    w.push2   = p.push + (u64)(2u * wg) * (u32)p.push_cap;
+    w.bt2     = p.bt + (u64)(2u * wg) * (u32)p.bt_cap;
+    const u64 log_off = (u64)wg * (u32)p.log_cap;
+    w.log_key = p.log_key + log_off;
+    w.log_pu  = p.log_pu + log_off;
+    w.arch    = p.arch + (u64)wg * (u32)p.arch_cap;
     return w;
 }
 __device__ __forceinline__ void lds_add_u32(u32* cell, u32 v) {
@@ -262,7 +267,7 @@ __device__ __forceinline__ void sk_edge_stream(KP p, CtlS* ctl, const PushEntry*
     // (ranges are dealt from the last wave down, so that a level of a few units lands on wave 0, 1, ...: the waves that were
     //  dispatched first win the issue arbitration against younger waves, and a small level is a latency chain of one wave)
     const u32 slot = kWaves - 1u - wave;
-    const u32 u_lo = (u32)(((u64)slot * units) / kWaves), u_hi = (u32)(((u64)(slot + 1) * units) / kWaves);
+    const u32 u_lo = (slot * units) / kWaves, u_hi = ((slot + 1u) * units) / kWaves;    // (units < 2^26, slot < 16: 32 bits hold the products)
     if (u_lo >= u_hi || n_ent == 0) return;
     const bool small = n_ent <= 64u;                                           // (wave-uniform) the whole list in one wave
     u32 btv = 0, bt_first = 0;
@@ -433,15 +438,15 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
     KP p = kparams();
     lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs); capx = uni(capx);
     pu_base = uni(pu_base); parts = uni(parts); part = uni(part);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     const u32 lane = threadIdx.x & 63u;
     int* lk = w.log_key + seg_base; unsigned short* lp = w.log_pu + seg_base;
     double* S = MODE == 0 ? w.xvals + capx : nullptr;
     // (the boundary table's head was also written to LDS by the SCAN that built the push list: one global round trip less in
     //  front of the first entry load of every level of <= bt_l_cap * 64 edges
     //  -- but a partition walk (MODE 3) runs after a SCAN has written the NEXT list's table head there)
-    const u32* btp = MODE != 3 && ((E + 63u) >> 6) <= w.bt_l_cap ? (const u32*)w.bt_l : (const u32*)(w.bt2 + (size_t)cur * p.bt_cap);
-    sk_edge_stream<BLOCK, MODE != 0>(p, w.ctl, w.push2 + (size_t)cur * p.push_cap, btp, n_ent, E, S, MODE != 3 ? lp : nullptr, pu_base,
+    const u32* btp = MODE != 3 && ((E + 63u) >> 6) <= w.bt_l_cap ? (const u32*)w.bt_l : (const u32*)(w.bt2 + (u64)cur * (u32)p.bt_cap);
+    sk_edge_stream<BLOCK, MODE != 0>(p, w.ctl, w.push2 + (u64)cur * (u32)p.push_cap, btp, n_ent, E, S, MODE != 3 ? lp : nullptr, pu_base,
                                      [&](const int (&v)[4], const double (&sh)[4], u32 t0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -482,7 +487,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
 {
     KP p = kparams();
     lds0 = uni(lds0); seg_base = uni(seg_base); n = uni(n); capx = uni(capx); pu_base = uni(pu_base); parts = uni(parts); part = uni(part);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     const float thr = p.sk_thr_f;
     const u32 dshift = (u32)p.deg_shift;                                              // (a kernel-argument read inside the loop is re-issued behind every asm block)
     const double* S = w.xvals + capx;
@@ -525,13 +530,13 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
     typedef u32    u4 __attribute__((ext_vector_type(4)));
     KP p = kparams();
     lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); clear_n = uni(clear_n); pu_next = uni(pu_next); cnext = uni(cnext);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     CtlS* ctl = w.ctl;
     int* lkeys = w.xkeys; double* lvals = w.xvals;
     const u32 C = w.CX;
     LevelCtr* nx = &ctl->lc[nx_sel];
-    PushEntry* push = w.push2 + (size_t)nxt_sel * p.push_cap;
-    u32* bt_g = w.bt2 + (size_t)nxt_sel * p.bt_cap;
+    PushEntry* push = w.push2 + (u64)nxt_sel * (u32)p.push_cap;
+    u32* bt_g = w.bt2 + (u64)nxt_sel * (u32)p.bt_cap;
     const int tid = threadIdx.x, lane = tid & 63;
     SKT2(ctl, 4);
     if (clear_n) {
@@ -646,7 +651,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
     lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs);
     has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); nx_sel = uni(nx_sel);
     pu_base = uni(pu_base); pu_next = uni(pu_next); cnext = uni(cnext);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     CtlS* ctl = w.ctl; int* lkeys = w.xkeys; double* lvals = w.xvals;
     const u32 lane = threadIdx.x & 63u;
     const u32 cap = kMinCap;
@@ -655,9 +660,9 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
     u32* list = (u32*)((unsigned char*)ctl + kCtlStruct + 64 * kFlatW);     // the flag areas of the other waves (>= 257 words): they are parked
     static_assert((BLOCK / 64 - 1) * 64 * kFlatW >= 4 * (kSkSoloEdges + 1), "the claimed-slot list lives in the parked waves' flag bytes");
     LevelCtr* nx = &ctl->lc[nx_sel];
-    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
-    PushEntry* push_nxt = w.push2 + (size_t)(cur ^ 1u) * p.push_cap;
-    u32* bt_nxt = w.bt2 + (size_t)(cur ^ 1u) * p.bt_cap;
+    const PushEntry* push_cur = w.push2 + (u64)cur * (u32)p.push_cap;
+    PushEntry* push_nxt = w.push2 + (u64)(cur ^ 1u) * (u32)p.push_cap;
+    u32* bt_nxt = w.bt2 + (u64)(cur ^ 1u) * (u32)p.bt_cap;
     int* lk = w.log_key + seg_base; unsigned short* lp = w.log_pu + seg_base;
     // ---- the one step of the edge enumeration (as sk_edge_stream: entries flag their first edge, ballot, mbcnt, bpermute)
     const PushEntry ent = push_cur[min(lane, n_ent - 1u)];
@@ -939,7 +944,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
 {
     KP p = kparams();
     lds0 = uni(lds0); row_lo = uni(row_lo); row_hi = uni(row_hi); seed = uni(seed); n_pu = uni(n_pu); n_log = uni(n_log);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     CtlS* ctl = w.ctl;
     const SkTop t = sk_top(p, w, TG ? 0u : n_pu);
     const long long row = (long long)(((u64)row_hi << 32) | row_lo);
@@ -1068,7 +1073,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_wipe(u32 lds0, u32 what, u32 n, u32 a
     typedef u32 u4 __attribute__((ext_vector_type(4)));
     KP p = kparams();
     lds0 = uni(lds0); what = uni(what); n = uni(n); at = uni(at);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     const u4 z = {0u, 0u, 0u, 0u};
     if (what == 1u) {
         for (u32 i = 4u * threadIdx.x; i < w.MR + w.MU; i += 4u * BLOCK) *(u4*)&w.R[i] = z;     // R and U are adjacent
@@ -1095,7 +1100,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
 {
     KP p = kparams();
     lds0 = uni(lds0); seed = uni(seed);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     CtlS* ctl = w.ctl;
     const int tid = threadIdx.x;
     const u32 L = (u32)p.n_coef - 1u;
@@ -1104,8 +1109,8 @@ __device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
     const u32 s_start = seed_unit << kSkUnitShift;
     const int seed_key = (int)(seed_unit | (min(seed_deg, p.deg_sat) << p.deg_shift));
     const u32 pu_cap = (u32)min((u64)kSkMaxPushers, p.arch_cap);
-    PushEntry* push1 = w.push2 + (size_t)1 * p.push_cap;
-    u32* bt1 = w.bt2 + (size_t)1 * p.bt_cap;
+    PushEntry* push1 = w.push2 + (u64)(u32)p.push_cap;
+    u32* bt1 = w.bt2 + (u64)(u32)p.bt_cap;
     const bool room = p.log_cap > 0 && pu_cap >= 2u && p.push_cap > 0;
     bool pushes = false; double share = 0.0;
     if (L > 0 && seed_deg != 0 && 1.0 >= p.rmax * (double)seed_deg) {                // graph.h:94
@@ -1139,7 +1144,7 @@ __device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl)
 {
     KP p = kparams();
     lds0 = uni(lds0); lvl = uni(lvl);
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     CtlS* ctl = w.ctl;
     const int tid = threadIdx.x;
     const u32 CX = w.CX;
@@ -1282,7 +1287,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KP p = kparams();
     const u32 lds0 = uni(lds_addr(smem));
-    const SkView w = sk_view(p, lds0);
+    const SkView w = sk_view<BLOCK>(p, lds0);
     CtlS* ctl = w.ctl;
     const int tid = threadIdx.x;
     phase_sk_wipe<BLOCK>(lds0, 1u, 0u, 0u);

@@ -74,11 +74,15 @@ struct CtlS {
     u64 kth_bits;                         // smallest selected value (bit pattern)
     u32 bcnt[64];                         // select: binade counters
     u64 st[8], st_row[8];                 // statistics: workgroup totals / the row in flight
-    double coef[kSkMaxCoef];
+    double coef[kSkMaxCoef + 1];           // ([n_coef .. kSkMaxCoef]: never used -- a level reads coef[level + 1] unconditionally)
     u32 cand_q[kSkMaxCoef];               // per level: exact-table nodes per pushed edge of this workgroup's earlier rows (x 1.25, in 1/1024)
     int seed_key; u32 tot_pu, tot_log;    // the row in flight: its seed's key; pushers numbered and log records written so far
     double lv_dang; u32 lv_has_dang;      // the level in flight: mass its dangling nodes return to the seed (thread 0 writes them at the top of the level and is their only reader: STREAM's tail)
     u32 max_e, max_log;                   // largest level / log this workgroup has seen (statistics)
+    // launch constants the level loop needs, derived ONCE per workgroup (gfpush_sk_rows): read in the same batch of LDS reads as the
+    // level's state.  (From the kernel arguments they were five scalar loads per level and wave, each behind its own wait -- the
+    // compiler keeps the ADDRESSES of kernel arguments across calls, not their values -- and a fp64 division for the one-wave test.)
+    u32 k_log_cap, k_pu_cap, k_direct_max, k_solo_ok, k_cx, k_pad; double k_rscale;
 #ifdef GP_SK_TIMING
     u64 tacc[16]; u64 tlast;              // -DGP_SK_TIMING: 100 MHz ticks thread 0 spent per phase (flushed to the diag_sub counters)
     u64 tacc2[14]; u64 tlast2;            // ... and inside FILTER / SCAN / STREAM (tools/sk_phases.py)
@@ -1140,20 +1144,20 @@ __device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
 // One level l = 1..L of a row (graph.h:83-110).  Returns 0 when the row's levels are done (last level, dead frontier, or the row
 // leaves: ctl->fail), 1 to go on.  Every path out has passed the level's last barrier or has touched nothing shared.
 template <int BLOCK>
-__device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl)
+__device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl, u32 L)
 {
     KP p = kparams();
-    lds0 = uni(lds0); lvl = uni(lvl);
+    lds0 = uni(lds0); lvl = uni(lvl); L = uni(L);
     const SkView w = sk_view<BLOCK>(p, lds0);
     CtlS* ctl = w.ctl;
     const int tid = threadIdx.x;
-    const u32 CX = w.CX;
-    const u32 L = (u32)p.n_coef - 1u;
     const LevelCtr* in = &ctl->lc[(lvl & 1u) ^ 1u];
     LevelCtr* nx = &ctl->lc[lvl & 1u];
-    // ---- one batch of LDS reads: what the previous level left behind its last barrier
+    // ---- one batch of LDS reads: what the previous level left behind its last barrier, and the launch constants
     const u64 al_ = in->alloc, io_ = in->pad1; const u32 nd_ = in->n_dangling, fail_ = ctl->fail, q_ = ctl->cand_q[lvl]; const int sk_ = ctl->seed_key;
-    const double dg_ = in->dangling, c_ = ctl->coef[lvl], c1_ = ctl->coef[min(lvl + 1u, L)];
+    const double dg_ = in->dangling, c_ = ctl->coef[lvl], c1_ = ctl->coef[lvl + 1u], krs_ = ctl->k_rscale;
+    const u32 klc_ = ctl->k_log_cap, kpc_ = ctl->k_pu_cap, kdm_ = ctl->k_direct_max, kso_ = ctl->k_solo_ok, kcx_ = ctl->k_cx;
+    const u32 CX = uni(kcx_);
     const u64 al = uni(al_), io = uni(io_);
     const u32 n_ent_cur = (u32)al, e_cur = (u32)(al >> 32), pu_cur = (u32)io, log_pos = (u32)(io >> 32);
     const bool has_dang_cur = uni(nd_) != 0u;
@@ -1162,9 +1166,9 @@ __device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl)
     const u32 n_rec = e_cur + (has_dang_cur ? 1u : 0u);                           // log records (= pushed edges) of this level
     if (n_rec == 0 || uni(fail_)) return 0u;                                      // the frontier died: later levels add nothing
     const bool last = lvl == L;                                                   // graph.h:104-110: no push from the last level
-    const u32 pu_cap = (u32)min((u64)kSkMaxPushers, p.arch_cap);                  // pusher numbers the row may hand out
+    const u32 pu_cap = uni(kpc_);                                                 // pusher numbers the row may hand out
     // (fail = 1: a slab bound, counted for the host's slab sizing; anything else has its own number)
-    if ((u64)log_pos + n_rec > p.log_cap || (u64)pu_cur + n_ent_cur + 1u > pu_cap) { if (tid == 0) ctl->fail = 1; return 0u; }
+    if ((u64)log_pos + n_rec > (u64)uni(klc_) || (u64)pu_cur + n_ent_cur + 1u > pu_cap) { if (tid == 0) ctl->fail = 1; return 0u; }
     const u32 seg_base = log_pos;
     const u32 pu_next = pu_cur + n_ent_cur + (has_dang_cur ? 1u : 0u);            // pusher number of the NEXT list's entry 0
     const u32 cur = lvl & 1u;                                                     // the push list this level streams (level 0 wrote list 1)
@@ -1175,7 +1179,7 @@ __device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl)
         if (has_dang_cur) w.arch[pu_cur + n_ent_cur] = uni(c_) * dang_cur;        // graph.h:92: the record of the mass returned to the seed
         zstat(ctl, zLevels, 1);
     }
-    const double cs = uni(c_) * p.sk_rscale;                                      // reserve-sketch units per unit of share
+    const double cs = uni(c_) * uni(krs_);                                        // reserve-sketch units per unit of share
     const double cnext = last ? 0.0 : uni(c1_);
     SKT(ctl, 6);
     if (last) {
@@ -1185,7 +1189,7 @@ __device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl)
     }
     // a level goes straight into the exact table while its edges would fill three quarters of it (its nodes: fewer; cap 1/2 / 0.65 / 0.8 / 1
     // of the slots measured 23.50 / 23.42 / 23.36 / 23.85 ms)
-    const u32 direct_max = min(p.sk_direct_max, 3u * (CX / 4u));
+    const u32 direct_max = uni(kdm_);                                             // (= min(sk_direct_max, 3/4 of the slots))
     // a sketch level keeps its share table (one value per pusher, one for the dangling mass) behind the slots it uses; a level
     // with more pushers than that leaves room for (a hub's thousands of leaves all push) goes without the sketch, whatever its size
     const u32 s_n = n_ent_cur + 1u;
@@ -1204,9 +1208,9 @@ __device__ __forceinline__ u32 phase_sk_level(u32 lds0, u32 lvl)
     // a small level: one wave does it, the others park at one barrier (phase_sk_solo).
     // (a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
     //  hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax)
-    const bool solo = p.solo && direct && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&
-                      p.push_cap >= (u64)kSkSoloEdges + 4u && (u64)pu_next + kSkSoloEdges + 4u <= pu_cap &&
-                      (double)p.bt_cap >= (p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz) / (double)(1u << kUnitShift) + 4.0;
+    //  -- that part of the test does not change during a launch: k_solo_ok)
+    const bool solo = uni(kso_) && direct && e_cur <= kSkSoloEdges && n_ent_cur >= 1u && n_ent_cur <= 64u &&
+                      (u64)pu_next + kSkSoloEdges + 4u <= pu_cap;
     if (solo) {
         if (wave_id() == 0)
             phase_sk_solo<BLOCK>(lds0, cur, n_ent_cur, e_cur, seg_base, cs, has_dang_cur ? 1u : 0u, dang_cur, seed_key, lvl & 1u, pu_cur, pu_next, cnext);
@@ -1297,7 +1301,15 @@ __device__ __forceinline__ void gfpush_sk_rows()
     if (tid < 14) ctl->tacc2[tid] = 0;
 #endif
     if (tid < kSkMaxCoef) { ctl->cand_q[tid] = 0; if (tid < p.n_coef) ctl->coef[tid] = p.coef[tid]; }
-    if (tid == 0) { ctl->max_e = 0; ctl->max_log = 0; }
+    if (tid == 0) {
+        ctl->max_e = 0; ctl->max_log = 0;
+        ctl->k_log_cap = (u32)min(p.log_cap, (u64)0xFFFFFFFFu); ctl->k_pu_cap = (u32)min((u64)kSkMaxPushers, p.arch_cap);
+        ctl->k_direct_max = min(p.sk_direct_max, 3u * (w.CX / 4u)); ctl->k_cx = w.CX; ctl->k_rscale = p.sk_rscale;
+        // a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
+        // hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax, SURVEY.md A.1
+        ctl->k_solo_ok = p.solo && p.push_cap >= (u64)kSkSoloEdges + 4u &&
+                         (double)p.bt_cap >= (p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz) / (double)(1u << kUnitShift) + 4.0 ? 1u : 0u;
+    }
     const long long n_rows = p.n_seeds;
     const u32 L = (u32)p.n_coef - 1u;
 
@@ -1320,7 +1332,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
         GP_SYNC();
         SKT(ctl, 0); SKT_COUNT(ctl, 15, 1);
         for (u32 lvl = 1; lvl <= L; ++lvl)
-            if (!uni(phase_sk_level<BLOCK>(lds0, lvl))) break;
+            if (!uni(phase_sk_level<BLOCK>(lds0, lvl, L))) break;
         GP_SYNC();
         SKT(ctl, 6);
         if (!uni(ctl->fail)) {

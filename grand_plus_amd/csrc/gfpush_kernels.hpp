@@ -796,7 +796,7 @@ __device__ __forceinline__ void push_alloc(KP p, CTL* ctl, LevelCtr* nx, PushEnt
 struct Heavy { int* keys; u32 cap; double thr; };
 __device__ __forceinline__ Heavy heavy_view(KP p, Ctl* ctl) {
     Heavy h;
-    h.keys = (int*)(p.cand + (size_t)blockIdx.x * p.cand_cap);                       // idle until TOP-K turns tables into candidates
+    h.keys = (int*)(p.cand + (u64)(u32)blockIdx.x * (u32)p.cand_cap);                       // idle until TOP-K turns tables into candidates
     h.cap = (u32)min((u64)0xFFFFFFFFu, 4ull * p.cand_cap);
     h.thr = uni(ctl->thr_early);
     return h;
@@ -1130,7 +1130,7 @@ __device__ __forceinline__ void edge_stream(KP p, CTL* ctl, const PushEntry* pus
     // (ranges are dealt from the last wave down, so that a level of a few units lands on wave 0, 1, ...: the waves that were
     //  dispatched first win the issue arbitration against younger waves, and a small level is a latency chain of one wave)
     const u32 slot = kWaves - 1u - wave;
-    const u32 u_lo = (u32)(((u64)slot * units) / kWaves), u_hi = (u32)(((u64)(slot + 1) * units) / kWaves);
+    const u32 u_lo = (slot * units) / kWaves, u_hi = ((slot + 1u) * units) / kWaves;    // (units < 2^26, slot < 16: 32 bits hold the products)
     if (u_lo >= u_hi || n_ent == 0) return;
     const bool small = n_ent <= 64u;                                           // (wave-uniform) the whole list in one wave
 #ifdef GP_DIAG_HEAVY
@@ -1769,14 +1769,17 @@ __device__ __forceinline__ WgView wg_view(KP p, u32 lds0) {
     w.ctl = lds_at<Ctl>(lds0);
     w.lvals = lds_at<double>(lds0 + (u32)kCtlBytes);
     w.lkeys = lds_at<int>(lds0 + (u32)kCtlBytes + 8u * w.C);
-    const size_t wg = blockIdx.x;
-    w.push2   = p.push + wg * 2 * p.push_cap;
-    w.resg    = p.resg + wg * p.resg_cap;
-    w.log_key = p.log_key + wg * p.log_cap;
-    w.log_val = p.log_val + wg * p.log_cap;
-    w.cand    = p.cand + wg * p.cand_cap;
-    w.bucket  = p.bucket + wg * p.bucket_cap;
-    w.bt2     = p.bt + wg * 2 * p.bt_cap;
+    // (every slab capacity is below 2^32 records -- gfpush.hip:ensure_workspace refuses a workspace bound beyond that --: one
+    //  32 x 32 -> 64-bit scalar multiply per slab instead of a 64 x 64-bit one)
+    const u32 wg = blockIdx.x;
+    w.push2   = p.push + (u64)(2u * wg) * (u32)p.push_cap;
+    w.resg    = p.resg + (u64)wg * (u32)p.resg_cap;
+    const u64 log_off = (u64)wg * (u32)p.log_cap;
+    w.log_key = p.log_key + log_off;
+    w.log_val = p.log_val + log_off;
+    w.cand    = p.cand + (u64)wg * (u32)p.cand_cap;
+    w.bucket  = p.bucket + (u64)wg * (u32)p.bucket_cap;
+    w.bt2     = p.bt + (u64)(2u * wg) * (u32)p.bt_cap;
     return w;
 }
 #define GP_PHASE_NOINLINE static __attribute__((noinline))
@@ -1791,8 +1794,8 @@ __device__ GP_PHASE_HOT void phase_expand(u32 lds0, u32 cap, u32 cur, u32 n_ent,
     lds0 = uni(lds0); cap = uni(cap); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); part = uni(part); np = uni(np);
     has_dang = uni(has_dang); dang = uni(dang); seed_key = uni(seed_key); dry = uni(dry);
     const WgView w = wg_view(p, lds0);
-    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
-    expand_level<BLOCK, MODE != 1, MODE == 2>(p, w.ctl, w.lkeys, w.lvals, w.resg, cap, push_cur, w.bt2 + (size_t)cur * p.bt_cap,
+    const PushEntry* push_cur = w.push2 + (u64)cur * (u32)p.push_cap;
+    expand_level<BLOCK, MODE != 1, MODE == 2>(p, w.ctl, w.lkeys, w.lvals, w.resg, cap, push_cur, w.bt2 + (u64)cur * (u32)p.bt_cap,
                                               n_ent, E, part, np, dry != 0);
     if (threadIdx.x == 0 && has_dang && !dry) {                                                    // graph.h:92
         if (MODE == 2) res_add_direct(w.lkeys, w.lvals, p.node_mask, seed_key, dang);
@@ -1813,7 +1816,7 @@ __device__ GP_PHASE_HOT void phase_scan_dense(u32 lds0, u32 cap, u32 nx_sel, u32
     lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); c = uni(c); do_push = uni(do_push);
     const WgView w = wg_view(p, lds0);
     scan_level_dense<BLOCK>(p, w.ctl, &w.ctl->lc[nx_sel], w.lkeys, w.lvals, cap, w.C, w.log_key, w.log_val,
-                            w.push2 + (size_t)nxt_sel * p.push_cap, w.bt2 + (size_t)nxt_sel * p.bt_cap, c, do_push != 0);
+                            w.push2 + (u64)nxt_sel * (u32)p.push_cap, w.bt2 + (u64)nxt_sel * (u32)p.bt_cap, c, do_push != 0);
 }
 template <int BLOCK>
 __device__ GP_PHASE_NOINLINE void phase_scan_seedrow(u32 lds0, u32 seed_start, u32 seed_deg, double share, double c, u32 do_push)
@@ -1853,9 +1856,9 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
     unsigned char* wscr = (unsigned char*)ctl + kCtlStruct;                 // wave 0's flag bytes
     u32* list = (u32*)((unsigned char*)ctl + kCtlStruct + 64 * kFlatW);     // the flag areas of waves 1..5 (<= 257 claimed slots): those waves are parked
     LevelCtr* nx = &ctl->lc[lvl & 1u];
-    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
-    PushEntry* push_nxt = w.push2 + (size_t)(cur ^ 1u) * p.push_cap;
-    u32* bt_nxt = w.bt2 + (size_t)(cur ^ 1u) * p.bt_cap;
+    const PushEntry* push_cur = w.push2 + (u64)cur * (u32)p.push_cap;
+    PushEntry* push_nxt = w.push2 + (u64)(cur ^ 1u) * (u32)p.push_cap;
+    u32* bt_nxt = w.bt2 + (u64)(cur ^ 1u) * (u32)p.bt_cap;
     // ---- EXPAND: one step
     const PushEntry ent = push_cur[min(lane, n_ent - 1u)];
     const u32 off = lane < n_ent ? ent.off : 0xFFFFFFFFu;
@@ -1954,7 +1957,7 @@ __device__ GP_PHASE_NOINLINE void phase_scan_hbm(u32 lds0, u32 cap, u32 nx_sel, 
     lds0 = uni(lds0); cap = uni(cap); nx_sel = uni(nx_sel); nxt_sel = uni(nxt_sel); c = uni(c); do_push = uni(do_push);
     const WgView w = wg_view(p, lds0);
     scan_level<BLOCK, false, 4>(p, w.ctl, &w.ctl->lc[nx_sel], w.lkeys, w.lvals, w.resg, cap, w.log_key, w.log_val,
-                                w.push2 + (size_t)nxt_sel * p.push_cap, w.bt2 + (size_t)nxt_sel * p.bt_cap, c, do_push != 0);
+                                w.push2 + (u64)nxt_sel * (u32)p.push_cap, w.bt2 + (u64)nxt_sel * (u32)p.bt_cap, c, do_push != 0);
 }
 
 // The empty LDS table (start of the kernel, after TOP-K used the region as scratch, after an overflowing partition).
@@ -1987,7 +1990,7 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
     Ctl* ctl = w.ctl;
     int* lkeys = w.lkeys; double* lvals = w.lvals;
     const int tid = threadIdx.x;
-    const PushEntry* push_cur = w.push2 + (size_t)cur * p.push_cap;
+    const PushEntry* push_cur = w.push2 + (u64)cur * (u32)p.push_cap;
     ResRec* bucket = w.bucket;
     u64 t0 = 0, t1 = 0, t2 = 0; (void)t0; (void)t1; (void)t2;
     // SCATTER into fixed-stride buckets: hash buckets of one level are nearly equal, and the
@@ -2000,7 +2003,7 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
     GP_SYNC();
     GP_STAMP(t0);
     // one lane per edge, like EXPAND
-    edge_stream<BLOCK>(p, ctl, push_cur, w.bt2 + (size_t)cur * p.bt_cap, n_ent, E, false,
+    edge_stream<BLOCK>(p, ctl, push_cur, w.bt2 + (u64)cur * (u32)p.bt_cap, n_ent, E, false,
                        [&](const int (&v)[4], const double (&sh)[4], u32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -2240,7 +2243,7 @@ __device__ __forceinline__ void gfpush_rows()
         //      EXPAND/SCAN round trip (two barriers, a table walk and a dependent indptr load) per row.
         {
             const double c0 = uni(ctl->coef[0]);
-            PushEntry* push_nxt0 = push2 + (size_t)1 * p.push_cap;
+            PushEntry* push_nxt0 = push2 + (u64)(u32)p.push_cap;
             if (tid == 0) {
                 if (p.log_cap > 0) { log_key[0] = seed_key; log_val[0] = c0; }                         // graph.h:90 / :109
                 else ctl->fail = 1;
@@ -2269,7 +2272,7 @@ __device__ __forceinline__ void gfpush_rows()
                         }
                         // the one entry contains every 64-edge boundary of the level (a hub seed: many)
                         const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
-                        u32* bt_g = w.bt2 + (size_t)1 * p.bt_cap;
+                        u32* bt_g = w.bt2 + (u64)(u32)p.bt_cap;
                         if (seedrow) { }
                         else if ((u64)units > p.bt_cap) { if (tid == 0) ctl->fail = 1; }
                         else

@@ -960,7 +960,12 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
     // SCAN left them in HBM with the push-list entries; the level sketch's bytes they land in are dead.
     if (!TG) for (u32 i = tid; i < n_pu; i += BLOCK) t.T[i] = w.arch[i];
     for (u32 i = tid; i < 512u; i += BLOCK) t.fine[i] = 0;
-    if (tid == 0) { ctl->ovf = 0; ctl->tk_t = 1u; }
+    // (the first round's aggregation table and select counters are made ready here, in front of a barrier that is there anyway:
+    //  two barriers fewer per row than wiping at the top of the round)
+    for (u32 i = tid; i < t.CA; i += BLOCK) { t.akeys[i] = kEmpty; t.avals[i] = 0.0; }
+    if (tid < 64) ctl->bcnt[tid] = 0;
+    if (tid == 0) { ctl->ovf = 0; ctl->tk_t = 1u; ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
+    bool table_ready = true;
     GP_SYNC();
     // ---- t_c: the cell value of rank ~ target, off a histogram over (binade, top 4 mantissa bits) of the cells
     for (u32 i = tid; i < t.MR; i += BLOCK) {
@@ -1002,11 +1007,14 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 const u32 n_run = part == 0 ? 0u : need;
                 Cand mine; mine.bits = 0; mine.key = kEmpty; mine.pad = 0;
                 if ((u32)tid < n_run) mine = t.sel[tid];                              // (K <= 128 <= BLOCK)
-                GP_SYNC();
-                for (u32 i = tid; i < t.CA; i += BLOCK) { t.akeys[i] = kEmpty; t.avals[i] = 0.0; }
-                if (tid < 64) ctl->bcnt[tid] = 0;
-                if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
-                GP_SYNC();
+                if (!table_ready) {
+                    GP_SYNC();
+                    for (u32 i = tid; i < t.CA; i += BLOCK) { t.akeys[i] = kEmpty; t.avals[i] = 0.0; }
+                    if (tid < 64) ctl->bcnt[tid] = 0;
+                    if (tid == 0) { ctl->n_sel = 0; ctl->n_tie = 0; ctl->tk_wide = 0; ctl->kth_bits = ~0ull; }
+                    GP_SYNC();
+                }
+                table_ready = false;
                 if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
                 auto tabled = [&](const int (&k)[4], const u32 (&pu)[4]) {
                     u32 cell[4]; double cv[4];

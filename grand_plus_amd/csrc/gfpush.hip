@@ -112,6 +112,7 @@ struct gp_graph {
     int num_cus = 0;
     // options
     int block_threads = 0; int lds_bytes = 0; int max_workgroups = 0;     // 0 = choose per graph
+    int verify_merge = 0;                                                 // gp_gfpush re-checks every merged row against the slab once the launches have retired (option "verify_merge")
     int lds_pad = 0; int pretouch = 0;                                    // experiment knobs: extra dynamic LDS per workgroup that the tables do not use (forces fewer workgroups per CU); memset the workspace when it is allocated
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
     int kernel = 0;                                                        // option: 0 = choose per call, 1 = general kernel, 2 = sketch kernel whenever the call allows it
@@ -836,6 +837,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "measure_choice") {
         g->measure_choice = value ? 1 : 0;       // 0 = kernel and launch shape from the rmax / graph-size thresholds alone (what calls below 4 096 rows always get)
         if (!value) g->choices.clear();
+    } else if (k == "verify_merge") {
+        g->verify_merge = value ? 1 : 0;
     } else if (k == "pretouch") {
         g->pretouch = value ? 1 : 0;             // memset the whole workspace when it is allocated (slow-phase experiment)
     } else if (k == "max_workgroups") {
@@ -1327,6 +1330,23 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
     // every launch has retired: what is still on its way arrives within microseconds
     for (int spin = 0; n_merged != n_seeds && spin < 2000000; ++spin) sweep();
     if (n_merged != n_seeds) return fail(GP_ERR_HIP, "%lld of %lld rows never arrived in host memory", (long long)(n_seeds - n_merged), (long long)n_seeds);
+    if (g->verify_merge) {
+        // The merge rule -- a row is taken once every filled slot has left the sentinel pattern in all three arrays -- rests on an
+        // 8-byte value store never arriving torn and on no slot being rewritten after it first arrived.  With
+        // the launches retired the slab holds the rows as the kernels left them: every row merged WHILE the kernel ran must equal it.
+        int64_t bad = 0, first_bad = -1;
+        for (int64_t it = 0; it < n_seeds; ++it) {
+            const int nf = h_filled[it];
+            const int64_t o = it * (int64_t)K;
+            const bool same = nf >= 0 && nf <= K &&
+                              std::memcmp(row_idx + o, (const void*)(h_row + o), sizeof(int) * (size_t)nf) == 0 &&
+                              std::memcmp(col_idx + o, (const void*)(h_col + o), sizeof(int) * (size_t)nf) == 0 &&
+                              std::memcmp(value + o, (const void*)(h_val + o), sizeof(double) * (size_t)nf) == 0;
+            if (!same) { ++bad; if (first_bad < 0) first_bad = it; }
+        }
+        if (bad) return fail(GP_ERR_HIP, "verify_merge: %lld of %lld rows were merged before they had fully arrived (first: row %lld)",
+                             (long long)bad, (long long)n_seeds, (long long)first_bad);
+    }
     return GP_OK;
 }
 

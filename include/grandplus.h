@@ -202,6 +202,9 @@ int gp_reset_stats(gp_graph* g);
  *   "sk_block_threads" / "sk_lg_mu" / "sk_lg_mr" / "sk_target"   geometry of the sketch kernel (0 = default): threads per
  *                      workgroup (512 = three per CU with 52 KB, 768 = two with 80 KB), log2 cells of the level sketch and
  *                      of the reserve sketch, cell rank of the first TOP-K threshold (default 4 K)
+ *   "verify_merge"    1 = gp_gfpush (host buffers) compares every row it merged while the kernel was running with the pinned
+ *                      slab once the launches have retired and fails with GP_ERR_HIP if one differs (a debugging aid: the
+ *                      merge rule relies on stores to host memory arriving whole; default 0)
  *   "diag_flags"      ignored by the product library; the diagnostic build (-DGP_DIAG) skips phases for
  *                      instruction attribution (bit 0: TOP-K) -- its results are then meaningless
  * Returns GP_ERR_INVALID_ARG for an unknown key or an out-of-range value.

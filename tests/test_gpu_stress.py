@@ -47,3 +47,30 @@ def test_repeated_launches_agree(shape, recipe, kernel):
     exp, ost = _oracle(indptr, indices, seeds[sub], r.coef(), r.rmax, K)
     last = tuple(a.reshape(ROWS, K)[sub].reshape(-1) for a in runs[-1][0])
     _assert_parity(seeds[sub], K, last, exp, next_value=ost["next_value"], label=f"stress {shape} kernel {kernel}")
+
+
+@pytest.mark.parametrize("kernel", [2, 1])
+def test_host_path_merges_only_rows_that_have_fully_arrived(kernel):
+    """gp_gfpush merges a row out of the pinned slab while the kernel is still running, as soon as every filled
+    slot has left the sentinel pattern.  With option verify_merge the call re-checks every merged row against the slab once the
+    launches have retired and fails if one differs -- six 16 384-row calls per kernel on the MAG shape (K = 32: 512 bytes per row
+    arriving as posted PCIe writes), alternating slabs, and the rows of the last call against the device-resident path."""
+    import torch
+    from grand_plus_amd import Graph, synth
+    from grand_plus_amd.recipes import RECIPES
+    indptr, indices = synth.shape_csr("mag")
+    r = RECIPES[("mag", "ppr")]
+    K = r.top_k
+    seeds = synth.seeds(len(indptr) - 1, ROWS)
+    g = Graph(indptr, indices, 0)
+    g.set_option("kernel", kernel); g.set_option("verify_merge", 1)
+    row = np.zeros(ROWS * K, np.int32); col = np.zeros(ROWS * K, np.int32); val = np.zeros(ROWS * K)
+    for _ in range(REPS):
+        row[:] = 0; col[:] = 0; val[:] = 0.0
+        g.gfpush_omp(seeds.astype(np.int64), row, col, val, r.coef(), r.rmax, K)      # raises if a merged row differs from the slab
+    drow, dcol, dval, filled = g.gfpush_device(torch.from_numpy(seeds).cuda(), r.coef(), r.rmax, K)
+    f = filled.cpu().numpy()
+    keep = (np.arange(K)[None, :] < f[:, None]).reshape(-1)
+    dev = (np.where(keep, drow.cpu().numpy(), 0), np.where(keep, dcol.cpu().numpy(), 0), np.where(keep, dval.cpu().numpy(), 0.0))
+    g.close()
+    _assert_parity(seeds, K, (row, col, val), dev)

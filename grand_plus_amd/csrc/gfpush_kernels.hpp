@@ -1111,8 +1111,9 @@ __device__ __forceinline__ void res_add_any(int* lkeys, double* lvals, ResRec* r
 // the entry load of step s+2 are in flight.  Every wait of an iteration sits at its top, so the loads issued behind it may
 // be conditional without the compiler's wait counts turning conservative; lanes without an edge load the sentinel word
 // indices[nnz] = -1 (all four column loads of a step are unconditional).  f(col[4], share[4], t0) is called once per step;
-// col < 0 = no edge; lane i of window w holds edge number t0 + 64 w + i of the level.
-template <int BLOCK, class CTL, class F>
+// col < 0 = no edge; lane i of window w holds edge number t0 + 64 w + i of the level.  OWN: f(col[4], owner[4], t0) instead --
+// the push-list entry every edge belongs to, for callers that record WHERE an edge's share is rather than the share itself.
+template <int BLOCK, bool OWN = false, class CTL, class F>
 __device__ __forceinline__ void edge_stream(KP p, CTL* ctl, const PushEntry* push, const u32* bt,
                                             u32 n_ent, u32 E, bool dry, F f)
 {
@@ -1176,13 +1177,14 @@ __device__ __forceinline__ void edge_stream(KP p, CTL* ctl, const PushEntry* pus
     fetch_next(0);                           // t0n = t1n = 0: takes the regular branch
 
     int nc[4] = {-1, -1, -1, -1}; double ns[4] = {0.0, 0.0, 0.0, 0.0};     // columns in flight and their shares
+    u32 no[4] = {0, 0, 0, 0};                                              // ... or the entries they belong to (OWN)
     u32 nt0 = 0;                                                           // ... and the number of their first edge
     bool have_cols = false;
     // One loop: match the next step's edges to its entries (LDS only), take over the columns of the step before (their loads
     // have been in flight since the previous iteration), issue the next step's column loads and the entry load of the step
     // after it, insert.  Every wait of an iteration sits at its top, so the loads issued behind may be conditional.
     do {
-        u32 idx[4]; double sh[4]; u32 end = 0;
+        u32 idx[4]; double sh[4]; u32 own[4]; u32 end = 0;
         if (have_ent) {
             // edge -> entry for the edges [t0n, t1n) given the entries from i0n on
             const u32 cnt = min(64u, n_ent - i0n);
@@ -1216,12 +1218,13 @@ __device__ __forceinline__ void edge_stream(KP p, CTL* ctl, const PushEntry* pus
                 const u32 q = t0n + 64u * (u32)w + lane;
                 idx[w] = q < end ? rel_e + q : sentinel;                       // graph.h:97
                 sh[w] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                if constexpr (OWN) own[w] = i0n + (e[w] >> 2); else own[w] = 0u;
             }
         }
         GP_XS(0);
-        int cc[4]; double cs[4];
+        int cc[4]; double cs[4]; u32 co[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; cs[w] = ns[w]; }
+        for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; cs[w] = ns[w]; co[w] = no[w]; }
         const u32 ct0 = nt0;
 #ifdef GP_DIAG_HEAVY
         if (cc[0] == 0x7FFFFFF0 && cc[1] == 0x7FFFFFF0 && cc[2] == 0x7FFFFFF0 && cc[3] == 0x7FFFFFF0) xs[6] += 1;      // (uses the loaded values: the wait is charged here)
@@ -1231,11 +1234,11 @@ __device__ __forceinline__ void edge_stream(KP p, CTL* ctl, const PushEntry* pus
         have_cols = have_ent;
         if (have_ent) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; ns[w] = sh[w]; }
+            for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; if constexpr (OWN) no[w] = own[w]; else ns[w] = sh[w]; }
             nt0 = t0n;
             fetch_next(end);
         }
-        if (had_cols) f(cc, cs, ct0);
+        if (had_cols) { if constexpr (OWN) f(cc, co, ct0); else f(cc, cs, ct0); }
         GP_XS(2);
     } while (have_cols);
     GP_XS_FLUSH();
@@ -1991,7 +1994,15 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
     int* lkeys = w.lkeys; double* lvals = w.lvals;
     const int tid = threadIdx.x;
     const PushEntry* push_cur = w.push2 + (u64)cur * (u32)p.push_cap;
-    ResRec* bucket = w.bucket;
+    // The one-workgroup-per-CU shape (1024 threads x 160 KB: what recipes with rmax < 5e-6 on large graphs run, the Amazon2M line)
+    // writes 8-BYTE bucket records (round 5): the packed column word and the NUMBER of the push-list entry the edge belongs to.
+    // The pass that inserts a bucket gathers the fp64 share from that entry -- the level's push list (16 bytes per pusher, a few
+    // thousand pushers) stays in the L2 -- instead of carrying it through HBM with every edge: (key, pad, share) records of 16
+    // bytes, written once and read once, were 7 of that line's 16 MB per row at 4.6 TB/s of fabric traffic (measured: 42.9 ->
+    // 39.5 ms).  The smaller shapes keep the 16-byte records: their bucketed levels (Pubmed's peak levels) are short chains of
+    // latency, not bandwidth, and a dependent gather in front of the insert cost them 1 %.
+    constexpr bool kShortRec = BLOCK == 1024;
+    u64* bucket = (u64*)w.bucket; ResRec* bucket16 = w.bucket; (void)bucket; (void)bucket16;
     u64 t0 = 0, t1 = 0, t2 = 0; (void)t0; (void)t1; (void)t2;
     // SCATTER into fixed-stride buckets: hash buckets of one level are nearly equal, and the
     // buffer is sized for the worst level the bounds allow (E_max), typically ~10x this one, so
@@ -2003,6 +2014,19 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
     GP_SYNC();
     GP_STAMP(t0);
     // one lane per edge, like EXPAND
+    if constexpr (kShortRec) {
+    edge_stream<BLOCK, true>(p, ctl, push_cur, w.bt2 + (u64)cur * (u32)p.bt_cap, n_ent, E, false,
+                             [&](const int (&v)[4], const u32 (&own)[4], u32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (v[q] < 0) continue;
+            const u32 bk = slot_of(hash_b((u32)v[q]), P);
+            const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (i < stride) bucket[(u64)bk * stride + i] = ((u64)own[q] << 32) | (u32)v[q];
+            else ctl->bovf = 1;
+        }
+    });
+    } else {
     edge_stream<BLOCK>(p, ctl, push_cur, w.bt2 + (u64)cur * (u32)p.bt_cap, n_ent, E, false,
                        [&](const int (&v)[4], const double (&sh)[4], u32) {
 #pragma unroll
@@ -2010,10 +2034,11 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
             if (v[q] < 0) continue;
             const u32 bk = slot_of(hash_b((u32)v[q]), P);
             const u32 i = __hip_atomic_fetch_add(&ctl->bcnt[bk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (i < stride) { ResRec r; r.key = v[q]; r.pad = 0; r.val = sh[q]; bucket[(u64)bk * stride + i] = r; }
+            if (i < stride) { ResRec r; r.key = v[q]; r.pad = 0; r.val = sh[q]; bucket16[(u64)bk * stride + i] = r; }
             else ctl->bovf = 1;
         }
     });
+    }
     GP_SYNC();
     GP_STAMP(t1); GP_TK_ACC(0, t0, t1);
     if (ctl->bovf) return 0u;
@@ -2028,18 +2053,48 @@ __device__ GP_PHASE_NOINLINE u32 phase_bucketed_level(u32 lds0, u32 cap, u32 P, 
             GP_TK_ACC(2, 0, 1);
             const u32 want = b * Q + q, fine = P * Q;
             bool ok = true;
+            if constexpr (kShortRec) {
+            // (the records of the NEXT four windows are in flight while the shares of these are gathered and inserted; a third
+            //  stage -- the gathers issued one step ahead as well -- measured 40.7 against 39.5 ms)
+            u64 nx[4];
+            auto load4 = [&](u32 base) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const u32 i = base + (u32)u * BLOCK + tid;
+                    nx[u] = 0xFFFFFFFFull;                                                    // key -1 = kEmpty: no record
+                    if (i < hi) nx[u] = bucket[i];
+                }
+            };
+            if (lo < hi) load4(lo);
+            for (u32 base = lo; base < hi; base += 4 * BLOCK) {
+                u64 rr[4]; double sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rr[u] = nx[u];
+                if (base + 4 * BLOCK < hi) load4(base + 4 * BLOCK);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)                                                   // four gathers in flight
+                    sv[u] = (int)(u32)rr[u] != kEmpty ? push_cur[(u32)(rr[u] >> 32)].share : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int key = (int)(u32)rr[u];
+                    if (key != kEmpty && (Q == 1 || slot_of(hash_b((u32)key), fine) == want))
+                        ok &= res_add_lds(lkeys, lvals, cap, key, sv[u]);                     // graph.h:98
+                }
+            }
+            } else {
             for (u32 base = lo; base < hi; base += 4 * BLOCK) {
                 ResRec rr[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const u32 i = base + (u32)u * BLOCK + tid;
                     rr[u].key = kEmpty; rr[u].val = 0.0;
-                    if (i < hi) rr[u] = bucket[i];
+                    if (i < hi) rr[u] = bucket16[i];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (rr[u].key != kEmpty && (Q == 1 || slot_of(hash_b((u32)rr[u].key), fine) == want))
                         ok &= res_add_lds(lkeys, lvals, cap, rr[u].key, rr[u].val);          // graph.h:98
+            }
             }
             if (tid == 0 && has_dang && slot_of(hash_b((u32)seed_key), fine) == want)       // graph.h:92
                 ok &= res_add_lds(lkeys, lvals, cap, seed_key, dang);

@@ -12,6 +12,7 @@ bash tools/collect_profiles.sh $TAG > gpurun_out/$TAG/collect.log 2>&1
 tail -7 gpurun_out/$TAG/collect.log
 GRANDPLUS_LIB=libgrandplus_skt.so timeout 600 python tools/sk_phases.py mag 65536 > gpurun_out/$TAG/sk_phases.txt 2>&1
 GRANDPLUS_LIB=libgrandplus_skt.so timeout 600 python tools/sk_phases.py mag 4096 max_workgroups=8 >> gpurun_out/$TAG/sk_phases.txt 2>&1
+GRANDPLUS_DIAG=1 timeout 600 python tools/level_breakdown.py amazon2m > gpurun_out/$TAG/amazon2m_levels.txt 2>&1
 rm -rf gpurun_out/$TAG/trace 2>/dev/null
 GRANDPLUS_STRESS_REPS=30 GRANDPLUS_STRESS_ROWS=65536 timeout 900 python -m pytest tests/test_gpu_stress.py -q -x -k "2-mag or 2-reddit" 2>&1 | tail -3 > gpurun_out/$TAG/soak.txt
 cat gpurun_out/$TAG/soak.txt

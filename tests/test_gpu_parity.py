@@ -249,6 +249,30 @@ def test_partitioned_levels_small_lds():
         assert st0[k] == st1[k]
 
 
+def test_bucketed_levels_with_short_records_in_the_one_workgroup_per_cu_shape():
+    """Round 5: the 1024-thread shape writes 8-byte bucket records (column word + push-list entry number) and gathers the share
+    from the push list when it inserts a bucket.  A recipe without a threshold to speak of (rmax 1e-6: levels of tens of
+    thousands of edges on the 100 k-node shape) under a small table (1024 threads x 48 KB) makes most levels bucketed, hubs and
+    levels of <= 64 entries included; rows and exact counters must equal the oracle's and those of the default shape."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import make_coef
+    indptr, indices = synth.shape_csr("small")
+    n = len(indptr) - 1
+    deg = np.diff(indptr)
+    seeds = np.concatenate([synth.seeds(n, 40), np.argsort(deg)[-8:].astype(np.int32)])          # + the eight largest hubs
+    coef = make_coef("ppr", 5, 0.15)
+    rmax, K = 1e-6, 64
+    got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"kernel": 1, "block_threads": 1024, "lds_bytes": 49152, "exact_stats": 1})
+    base, st0 = _run_gpu(indptr, indices, seeds, coef, rmax, K, options={"kernel": 1, "exact_stats": 1})
+    exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
+    assert st["failed_rows"] == 0 and st["block_threads"] == 1024
+    _assert_parity(seeds, K, got, exp, next_value=ost["next_value"])
+    _assert_parity(seeds, K, base, exp, next_value=ost["next_value"])
+    for k in ("pushes", "edges", "filled", "support", "frontier"):
+        assert st[k] == st0[k]
+    assert st["pushes"] == ost["pushes"] and st["edges"] == ost["edges"]
+
+
 def test_device_api_matches_host_api():
     import torch
     from grand_plus_amd import Graph, synth

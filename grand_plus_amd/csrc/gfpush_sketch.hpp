@@ -256,9 +256,13 @@ __device__ __forceinline__ void log_groups2_nt(const int* lk, const unsigned sho
 // with two additions made where an edge is matched to its entry (not a register of the pipeline is spent on them): the edge's log
 // record gets its pusher number (pu_base + the owner's index in the push list; lp == nullptr: not wanted), and the entries a wave
 // holds in its lanes leave their share in the level's share table S (S == nullptr: not wanted).
-template <int BLOCK, bool NT, class F>
+// FX: what an edge carries of its entry's share.  0: the fp64 share (levels that insert into the exact table).  1: its two
+// fixed-point images -- ceil(share * 2^31) for the level sketch and ceil(share * cs) for the reserve sketch --, 2: the second only
+// (last level).  The images are computed ONCE PER ENTRY by the lane that holds it and travel through the same two ds_bpermute
+// that would move the share's halves: six fp64 operations per edge become six per pusher (a sketch level has 13 edges per pusher).
+template <int BLOCK, bool NT, int FX, class F>
 __device__ __forceinline__ void sk_edge_stream(KP p, CtlS* ctl, const PushEntry* push, const u32* bt, u32 n_ent, u32 E, double* S,
-                                               unsigned short* lp, u32 pu_base, F f)
+                                               unsigned short* lp, u32 pu_base, double cs, F f)
 {
     constexpr u32 kWaves = BLOCK / 64;
     static_assert(kFlatW == 4, "sk_edge_stream reads the four window flags of a lane as one 32-bit word");
@@ -301,11 +305,11 @@ __device__ __forceinline__ void sk_edge_stream(KP p, CtlS* ctl, const PushEntry*
     if (small) entn = push[min(lane, n_ent - 1u)];
     fetch_next(0);
 
-    int nc[4] = {-1, -1, -1, -1}; double ns[4] = {0.0, 0.0, 0.0, 0.0};
+    int nc[4] = {-1, -1, -1, -1}; double ns[4] = {0.0, 0.0, 0.0, 0.0}; u32 nu[4] = {0, 0, 0, 0}, nr[4] = {0, 0, 0, 0};
     u32 nt0 = 0;
     bool have_cols = false;
     do {
-        u32 idx[4]; double sh[4]; u32 end = 0;
+        u32 idx[4]; double sh[4] = {0.0, 0.0, 0.0, 0.0}; u32 su[4] = {0, 0, 0, 0}, sr[4] = {0, 0, 0, 0}; u32 end = 0;
         if (have_ent) {
             const u32 cnt = min(64u, n_ent - i0n);
             const u32 off = lane < cnt ? entn.off : 0xFFFFFFFFu;
@@ -329,33 +333,45 @@ __device__ __forceinline__ void sk_edge_stream(KP p, CtlS* ctl, const PushEntry*
                 before += (u32)__popcll(M);
             }
             const u64 sbits = (u64)__double_as_longlong(entn.share);
+            u32 eu = 0, er = 0;                                                // this lane's entry: its share in sketch units
+            if (FX == 1) eu = fx_up(entn.share * 2147483648.0);
+            if (FX != 0) er = fx_up(entn.share * cs);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const u32 rel_e = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)entn.rel);
-                const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)(u32)sbits);
-                const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)(u32)(sbits >> 32));
+                if (FX == 0) {
+                    const u32 lo = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)(u32)sbits);
+                    const u32 hi = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)(u32)(sbits >> 32));
+                    sh[w] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                }
+                if (FX == 1) su[w] = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)eu);
+                if (FX != 0) sr[w] = (u32)__builtin_amdgcn_ds_bpermute((int)(e[w] << 2), (int)er);
                 const u32 q = t0n + 64u * (u32)w + lane;
                 idx[w] = q < end ? rel_e + q : sentinel;                       // graph.h:97
-                sh[w] = __longlong_as_double((long long)(((u64)hi << 32) | lo));
                 if (lp && q < end) {                                           // graph.h:98 -> the record's pusher number
                     const unsigned short pu = (unsigned short)(pu_base + i0n + e[w]);
                     if (NT) __builtin_nontemporal_store(pu, &lp[q]); else lp[q] = pu;
                 }
             }
         }
-        int cc[4]; double cs[4];
+        int cc[4]; double csh[4]; u32 cu[4], cr[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; cs[w] = ns[w]; }
+        for (int w = 0; w < 4; ++w) { cc[w] = nc[w]; csh[w] = ns[w]; cu[w] = nu[w]; cr[w] = nr[w]; }
         const u32 ct0 = nt0;
         const bool had_cols = have_cols;
         have_cols = have_ent;
         if (have_ent) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { nc[w] = indices[idx[w]]; ns[w] = sh[w]; }
+            for (int w = 0; w < 4; ++w) {
+                nc[w] = indices[idx[w]];
+                if (FX == 0) ns[w] = sh[w];
+                if (FX == 1) nu[w] = su[w];
+                if (FX != 0) nr[w] = sr[w];
+            }
             nt0 = t0n;
             fetch_next(end);
         }
-        if (had_cols) f(cc, cs, ct0);
+        if (had_cols) f(cc, csh, cu, cr, ct0);
     } while (have_cols);
 }
 
@@ -450,8 +466,9 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
     //  front of the first entry load of every level of <= bt_l_cap * 64 edges
     //  -- but a partition walk (MODE 3) runs after a SCAN has written the NEXT list's table head there)
     const u32* btp = MODE != 3 && ((E + 63u) >> 6) <= w.bt_l_cap ? (const u32*)w.bt_l : (const u32*)(w.bt2 + (u64)cur * (u32)p.bt_cap);
-    sk_edge_stream<BLOCK, MODE != 0>(p, w.ctl, w.push2 + (u64)cur * (u32)p.push_cap, btp, n_ent, E, S, MODE != 3 ? lp : nullptr, pu_base,
-                                     [&](const int (&v)[4], const double (&sh)[4], u32 t0) {
+    sk_edge_stream<BLOCK, MODE != 0, MODE == 0 ? 1 : MODE == 2 ? 2 : 0>(p, w.ctl, w.push2 + (u64)cur * (u32)p.push_cap, btp, n_ent, E, S,
+                                     MODE != 3 ? lp : nullptr, pu_base, cs,
+                                     [&](const int (&v)[4], const double (&sh)[4], const u32 (&su)[4], const u32 (&sr)[4], u32 t0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (MODE != 3 && v[q] >= 0) {
@@ -460,8 +477,8 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
                 // read by TOP-K: non-temporal stores
                 if (MODE != 0) __builtin_nontemporal_store(v[q], &lk[li]); else lk[li] = v[q];
                 const u32 h = (u32)v[q] * kSkMulA;
-                if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(sh[q] * cs));       // graph.h:90 / :109, as an upper bound
-                if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], fx_up(sh[q] * 2147483648.0));
+                if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], MODE == 1 ? fx_up(sh[q] * cs) : sr[q]);       // graph.h:90 / :109, as an upper bound
+                if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], su[q]);
             }
         }
         if (MODE == 1) {                                                                  // graph.h:98, two windows' compare-and-swaps in flight together

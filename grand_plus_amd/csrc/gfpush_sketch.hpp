@@ -192,11 +192,16 @@ __device__ __forceinline__ void log_groups(const int* lk, const unsigned short* 
     for (;;) {
         int k[4]; u32 pu[4];
         const u32 i0 = g + 4u * lane;
+        if (g >= first && g + 256u <= end) {                              // (wave-uniform) a group inside the segment: nothing to mask
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool in = i0 + (u32)q >= first && i0 + (u32)q < end;
-            k[q] = in ? kn[q] : -1;
-            pu[q] = in ? (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu : 0u;
+            for (int q = 0; q < 4; ++q) { k[q] = kn[q]; pu[q] = (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = i0 + (u32)q >= first && i0 + (u32)q < end;
+                k[q] = in ? kn[q] : -1;
+                pu[q] = in ? (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu : 0u;
+            }
         }
         g += kStride;
         const bool more = g < end;                                    // wave-uniform
@@ -226,11 +231,16 @@ __device__ __forceinline__ void log_groups2_nt(const int* lk, const unsigned sho
     };
     auto consume = [&](u32 g0, const i4& kn, const u2& pn, int (&k)[4], u32 (&pu)[4]) {
         const u32 i0 = g0 + 4u * lane;
+        if (g0 + 256u <= end) {                                           // (wave-uniform) every group but the log's last: nothing to mask
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool in = i0 + (u32)q < end;
-            k[q] = in ? kn[q] : -1;
-            pu[q] = in ? (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu : 0u;
+            for (int q = 0; q < 4; ++q) { k[q] = kn[q]; pu[q] = (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = i0 + (u32)q < end;
+                k[q] = in ? kn[q] : -1;
+                pu[q] = in ? (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu : 0u;
+            }
         }
     };
     load(g, ka, pa);

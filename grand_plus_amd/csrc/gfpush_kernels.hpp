@@ -552,13 +552,17 @@ __device__ __forceinline__ void insert_window_asm(int* keys, double* vals, u32 c
 #define GP_IW4_F3(q)     "v_mul_lo_u32 %[se" #q "], %[se" #q "], %[st]\n\t"
 #define GP_IW4_F4(q)     "v_mul_hi_u32 %[se" #q "], %[se" #q "], %[parts]\n\t"
 #define GP_IW4_F5(q)     "v_cmp_eq_u32_e64 vcc, %[part], %[se" #q "]\n\t" "s_and_b64 %[m" #q "], %[m" #q "], vcc\n\t"
-#define GP_IW4_H1(q)     "v_mul_lo_u32 %[sl" #q "], %[c" #q "], %[st]\n\t"                        /* hash_a -> home slot */
+// (round 5) The home slot of these batched inserts comes from FULL-RATE 24-bit multiplies: v_mul_lo_u32 / v_mul_hi_u32 issue at a
+// quarter of the rate of an ordinary vector instruction on gfx950, and hash_a + slot_of are three of them per key -- 12 issue
+// slots per window where the whole window insert has ~30.  h = mul24(k, c1); h ^= h >> 15; h = mul24(h, c2); slot = mul24(h >> 16,
+// capm) >> 16 (capm < 2^16: LDS tables have at most a few thousand slots).  Only the low 24 bits of a key enter: a graph of more
+// than 2^24 units probes a little longer, nothing else.  sk_home() in gfpush_sketch.hpp is the same function in C++; the tables of
+// the sketch kernel are touched through these two only.
+#define GP_IW4_H1(q)     "v_mul_u32_u24 %[sl" #q "], 0x9e3779, %[c" #q "]\n\t"
 #define GP_IW4_H2(q)     "v_lshrrev_b32 %[se" #q "], 15, %[sl" #q "]\n\t" "v_xor_b32 %[sl" #q "], %[se" #q "], %[sl" #q "]\n\t"
-#define GP_IW4_H3(q)     "v_mul_lo_u32 %[sl" #q "], %[sl" #q "], %[st]\n\t"
-#define GP_IW4_H4(q)     "v_mul_hi_u32 %[sl" #q "], %[sl" #q "], %[capm]\n\t" "v_lshl_add_u32 %[se" #q "], %[sl" #q "], 2, %[kb]\n\t"
-#define GP_IW4_HASHES \
-        "s_mov_b32 %[st], 0x9e3779b1\n\t" GP_IW4_EACH(GP_IW4_H1) GP_IW4_EACH(GP_IW4_H2) \
-        "s_mov_b32 %[st], 0x85ebca77\n\t" GP_IW4_EACH(GP_IW4_H3) GP_IW4_EACH(GP_IW4_H4)
+#define GP_IW4_H3(q)     "v_mul_u32_u24 %[sl" #q "], 0x85ebcb, %[sl" #q "]\n\t" "v_lshrrev_b32 %[sl" #q "], 16, %[sl" #q "]\n\t"
+#define GP_IW4_H4(q)     "v_mul_u32_u24 %[sl" #q "], %[capm], %[sl" #q "]\n\t" "v_lshrrev_b32 %[sl" #q "], 16, %[sl" #q "]\n\t" "v_lshl_add_u32 %[se" #q "], %[sl" #q "], 2, %[kb]\n\t"
+#define GP_IW4_HASHES GP_IW4_EACH(GP_IW4_H1) GP_IW4_EACH(GP_IW4_H2) GP_IW4_EACH(GP_IW4_H3) GP_IW4_EACH(GP_IW4_H4)
 #define GP_IW4_WALK(q) \
         "v_cmpx_ne_u32 vcc, %[se" #q "], %[c" #q "]\n\t" \
         "v_cmpx_ne_u32 vcc, -1, %[se" #q "]\n\t" \
@@ -658,8 +662,7 @@ __device__ __forceinline__ void insert_windows2_asm(int* keys, double* vals, u32
     u32 sl0, sl1, se0, se1, st; u64 sv, ent;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b32 %[st], 0x9e3779b1\n\t" GP_IW2_EACH(GP_IW4_H1) GP_IW2_EACH(GP_IW4_H2)
-        "s_mov_b32 %[st], 0x85ebca77\n\t" GP_IW2_EACH(GP_IW4_H3) GP_IW2_EACH(GP_IW4_H4)
+        GP_IW2_EACH(GP_IW4_H1) GP_IW2_EACH(GP_IW4_H2) GP_IW2_EACH(GP_IW4_H3) GP_IW2_EACH(GP_IW4_H4)
         GP_IW2_EACH(GP_IW4_ISSUE_C)
         GP_IW4_RESOLVE_C(0, 1) GP_IW4_RESOLVE_C(1, 0)
         : [sl0] "=&v"(sl0), [sl1] "=&v"(sl1), [se0] "=&v"(se0), [se1] "=&v"(se1), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)

@@ -61,7 +61,7 @@ namespace gp {
 #endif
 constexpr int kSkMaxCoef = 40;            // levels the control block has room for (longer recipes: general kernel)
 constexpr u32 kSkTie     = 256;           // the select ranks at most this many candidates by comparison
-constexpr u32 kSkMulA    = 0x9E3779B1u;   // sketch hash: cell = top bits of key * kSkMulA
+constexpr u32 kSkMul24   = 0x9E3779u;     // sketch hash: cell = top bits of (low 24 bits of the key) * kSkMul24 -- a FULL-RATE multiply (sk_cell)
 
 struct CtlS {
     long long row;
@@ -145,6 +145,67 @@ __device__ __forceinline__ SkView sk_view(KP p, u32 lds0) {
     w.log_pu  = p.log_pu + log_off;
     w.arch    = p.arch + (u64)wg * (u32)p.arch_cap;
     return w;
+}
+// The sketch-cell hash of a key (cells are indexed by its top bits).  v_mul_u32_u24, not v_mul_lo_u32: the full 32 x 32-bit
+// multiply issues at a quarter of the rate, and this hash is computed per edge in STREAM and per record in FILTER and in TOP-K's sweep.
+// (Which nodes share a cell is irrelevant for a bound that only ever adds; the low 24 bits of a key are its unit number on every
+// graph of up to 2^24 units.)
+__device__ __forceinline__ u32 sk_cell(u32 key) { return __umul24(key, kSkMul24); }
+// Home slot of a key in this kernel's LDS tables: the C++ twin of GP_IW4_HASHES (gfpush_kernels.hpp), full-rate multiplies only.
+__device__ __forceinline__ u32 sk_home(u32 k, u32 cap) {
+    u32 h = __umul24(k, 0x9E3779u); h ^= h >> 15; h = __umul24(h, 0x85EBCBu);
+    return __umul24(h >> 16, cap - kProbeSpan) >> 16;
+}
+__device__ __forceinline__ bool sk_res_add_lds(int* keys, double* vals, u32 cap, int k, double v) {      // res_add_lds with this kernel's hash
+    u32 slot = sk_home((u32)k, cap);
+    const int seen = probe_cas_asm(keys, slot, k);
+    if (seen != kEmpty && seen != k) return false;
+    __hip_atomic_fetch_add(&vals[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
+}
+// insert_window_solo (gfpush_kernels.hpp) with this kernel's hash: the lane learns where its key lives (`slot`) and whether it
+// CLAIMED that slot (`seen` == kEmpty).  `seen` stays 0 in lanes without an edge.
+__device__ __forceinline__ void sk_insert_window_solo(int* keys, double* vals, u32 cap, u32* flag, int col, double sh, u32& slot, int& seen)
+{
+    u32 t, h, st; u64 sv, ent;
+    slot = 0; seen = 0;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_i32 vcc, -1, %[col]\n\t"
+        "s_cbranch_execz 5f\n\t"
+        "s_mov_b64 %[ent], exec\n\t"
+        "v_mul_u32_u24 %[h], 0x9e3779, %[col]\n\t"
+        "v_lshrrev_b32 %[t], 15, %[h]\n\t"
+        "v_xor_b32 %[h], %[t], %[h]\n\t"
+        "v_mul_u32_u24 %[h], 0x85ebcb, %[h]\n\t"
+        "v_lshrrev_b32 %[h], 16, %[h]\n\t"
+        "v_mul_u32_u24 %[slot], %[capm], %[h]\n\t"
+        "v_lshrrev_b32 %[slot], 16, %[slot]\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "1:\n\t"
+        "v_lshl_add_u32 %[t], %[slot], 2, %[kb]\n\t"
+        "ds_cmpst_rtn_b32 %[seen], %[t], %[emp], %[col]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmpx_ne_u32 vcc, %[seen], %[col]\n\t"
+        "v_cmpx_ne_u32 vcc, -1, %[seen]\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[slot], %[st], %[slot]\n\t"
+        "s_add_u32 %[st], %[st], 1\n\t"
+        "s_cmp_le_u32 %[st], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "v_mov_b32 %[t], 1\n\t"
+        "v_mov_b32 %[h], %[fa]\n\t"
+        "ds_write_b32 %[h], %[t]\n"
+        "2:\n\t"
+        "s_andn2_b64 exec, %[ent], exec\n\t"
+        "v_lshl_add_u32 %[t], %[slot], 3, %[vb]\n\t"
+        "ds_add_f64 %[t], %[sh]\n"
+        "5:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t] "=&v"(t), [h] "=&v"(h), [slot] "+v"(slot), [seen] "+v"(seen), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
+        : [col] "v"(col), [sh] "v"(sh), [emp] "v"(kEmpty),
+          [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
+        : "vcc", "scc", "memory");
 }
 __device__ __forceinline__ void lds_add_u32(u32* cell, u32 v) {
     __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -411,51 +472,6 @@ __device__ __forceinline__ void sk_push_alloc(KP p, CtlS* ctl, LevelCtr* nx, Pus
     }
 }
 
-// insert_window_asm of gfpush_kernels.hpp without the partition filter and with the hash constants as literals (six scalar
-// registers fewer: a small level's STREAM holds its whole enumeration state in scalars beside it, and one spilled scalar there is
-// a scratch round trip per call).
-__device__ __forceinline__ void insert_window_all_asm(int* keys, double* vals, u32 cap, u32* flag, int col, double sh)
-{
-    u32 t, h, slot, seen, st; u64 sv, ent;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "v_cmpx_lt_i32 vcc, -1, %[col]\n\t"                       // lanes that hold an edge
-        "s_cbranch_execz 5f\n\t"
-        "s_mov_b64 %[ent], exec\n\t"
-        "s_mov_b32 %[st], 0x9e3779b1\n\t"                         // hash_a -> home slot (its constants pass through the step counter's register)
-        "v_mul_lo_u32 %[h], %[col], %[st]\n\t"
-        "v_lshrrev_b32 %[t], 15, %[h]\n\t"
-        "v_xor_b32 %[h], %[t], %[h]\n\t"
-        "s_mov_b32 %[st], 0x85ebca77\n\t"
-        "v_mul_lo_u32 %[h], %[h], %[st]\n\t"
-        "v_mul_hi_u32 %[slot], %[h], %[capm]\n\t"
-        "s_mov_b32 %[st], 1\n"
-        "1:\n\t"
-        "v_lshl_add_u32 %[t], %[slot], 2, %[kb]\n\t"
-        "ds_cmpst_rtn_b32 %[seen], %[t], %[emp], %[col]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmpx_ne_u32 vcc, %[seen], %[col]\n\t"
-        "v_cmpx_ne_u32 vcc, -1, %[seen]\n\t"
-        "s_cbranch_execz 2f\n\t"
-        "v_add_u32 %[slot], %[st], %[slot]\n\t"
-        "s_add_u32 %[st], %[st], 1\n\t"
-        "s_cmp_le_u32 %[st], %[lim]\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "v_mov_b32 %[t], 1\n\t"                                   // probe limit reached: the lanes still searching give up
-        "v_mov_b32 %[h], %[fa]\n\t"
-        "ds_write_b32 %[h], %[t]\n"
-        "2:\n\t"
-        "s_andn2_b64 exec, %[ent], exec\n\t"                      // the lanes that found or claimed their slot
-        "v_lshl_add_u32 %[t], %[slot], 3, %[vb]\n\t"
-        "ds_add_f64 %[t], %[sh]\n"
-        "5:\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [t] "=&v"(t), [h] "=&v"(h), [slot] "=&v"(slot), [seen] "=&v"(seen), [sv] "=&s"(sv), [ent] "=&s"(ent), [st] "=&s"(st)
-        : [col] "v"(col), [sh] "v"(sh), [emp] "v"(kEmpty),
-          [capm] "s"(cap - kProbeSpan), [kb] "s"(lds_addr(keys)), [vb] "s"(lds_addr(vals)), [fa] "s"(lds_addr(flag)), [lim] "n"(kMaxProbe)
-        : "vcc", "scc", "memory");
-}
-
 // ---------------------------------------------------------------- STREAM
 // MODE 0: log + reserve sketch + level sketch U + share table.   MODE 1: log + reserve sketch + exact insert into X (small levels).
 // MODE 2: log + reserve sketch (last level; the first pass of a level without the sketch that is walked in partitions from the start).
@@ -486,7 +502,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
                 // graph.h:98 -> one log record per edge.  Only a sketch level's FILTER reads its records back soon; the others are next
                 // read by TOP-K: non-temporal stores
                 if (MODE != 0) __builtin_nontemporal_store(v[q], &lk[li]); else lk[li] = v[q];
-                const u32 h = (u32)v[q] * kSkMulA;
+                const u32 h = sk_cell((u32)v[q]);
                 if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], MODE == 1 ? fx_up(sh[q] * cs) : sr[q]);       // graph.h:90 / :109, as an upper bound
                 if (MODE == 0) lds_add_u32(&w.U[h >> w.shU], su[q]);
             }
@@ -501,12 +517,12 @@ __device__ GP_PHASE_NOINLINE void phase_sk_stream(u32 lds0, u32 cur, u32 n_ent, 
         const double dang = w.ctl->lv_dang; const int seed_key = w.ctl->seed_key;
         if (MODE != 3) {
             lk[E] = seed_key; lp[E] = (unsigned short)(pu_base + n_ent);
-            const u32 h = (u32)seed_key * kSkMulA;
+            const u32 h = sk_cell((u32)seed_key);
             if (cs != 0.0) lds_add_u32(&w.R[h >> w.shR], fx_up(dang * cs));
             if (MODE == 0) { lds_add_u32(&w.U[h >> w.shU], fx_up(dang * 2147483648.0)); S[n_ent] = dang; }
         }
         if ((MODE == 1 || (MODE == 3 && (parts == 1u || slot_of(hash_b((u32)seed_key), parts) == part))) &&
-            !res_add_lds(w.xkeys, w.xvals, capx, seed_key, dang)) w.ctl->ovf = 1;
+            !sk_res_add_lds(w.xkeys, w.xvals, capx, seed_key, dang)) w.ctl->ovf = 1;
     }
 }
 
@@ -528,7 +544,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
         u32 cell[4]; double s[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                                                 // eight lookups in flight
-            cell[q] = w.U[((u32)max(k[q], 0) * kSkMulA) >> w.shU];
+            cell[q] = w.U[sk_cell((u32)max(k[q], 0)) >> w.shU];
             s[q] = S[k[q] >= 0 ? pu[q] - pu_base : 0u];
         }
         int kc[4];
@@ -733,10 +749,10 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
             const u32 li = q < 4 ? 64u * (u32)q + lane : E;
             __builtin_nontemporal_store(kq, &lk[li]);                                 // graph.h:98 -> one log record per edge (next read by TOP-K)
             __builtin_nontemporal_store((unsigned short)(pu_base + (q < 4 ? own[q < 4 ? q : 0] : n_ent)), &lp[li]);
-            if (cs != 0.0) lds_add_u32(&w.R[((u32)kq * kSkMulA) >> w.shR], fx_up(vq * cs));
+            if (cs != 0.0) lds_add_u32(&w.R[sk_cell((u32)kq) >> w.shR], fx_up(vq * cs));
         }
         u32 slot; int seen;
-        insert_window_solo(lkeys, lvals, cap, &ctl->ovf, kq, vq, slot, seen);
+        sk_insert_window_solo(lkeys, lvals, cap, &ctl->ovf, kq, vq, slot, seen);
         const bool fresh = kq >= 0 && seen == kEmpty;                       // this lane claimed the slot: a new frontier node
         const u64 M = __ballot(fresh);
         if (fresh) list[n_list + lane_prefix(M)] = slot;
@@ -1042,12 +1058,12 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                     GP_SYNC();
                 }
                 table_ready = false;
-                if (mine.key != kEmpty && !res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
+                if (mine.key != kEmpty && !sk_res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
                 auto tabled = [&](const int (&k)[4], const u32 (&pu)[4]) {
                     u32 cell[4]; double cv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {                                     // eight lookups in flight
-                        cell[q] = t.R[((u32)max(k[q], 0) * kSkMulA) >> t.shR];
+                        cell[q] = t.R[sk_cell((u32)max(k[q], 0)) >> t.shR];
                         cv[q] = TG ? w.arch[pu[q]] : t.T[pu[q]];
                     }
                     int kh[4];
@@ -1162,7 +1178,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
         ctl->seed_key = seed_key; ctl->tot_pu = 1; ctl->tot_log = 1;
         if (room) { w.log_key[0] = seed_key; w.log_pu[0] = 0; w.arch[0] = ctl->coef[0]; }      // graph.h:90
         if (!room || (pushes && (u64)units > p.bt_cap)) ctl->fail = 1;
-        lds_add_u32(&w.R[((u32)seed_key * kSkMulA) >> w.shR], fx_up(ctl->coef[0] * p.sk_rscale));
+        lds_add_u32(&w.R[sk_cell((u32)seed_key) >> w.shR], fx_up(ctl->coef[0] * p.sk_rscale));
         zstat(ctl, zLevels, 1);
         LevelCtr* l0 = &ctl->lc[0];
         l0->dangling = L > 0 && seed_deg == 0 ? 1.0 : 0.0; l0->n_dangling = L > 0 && seed_deg == 0 ? 1u : 0u;   // graph.h:91-93

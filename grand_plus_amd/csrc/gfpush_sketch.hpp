@@ -448,13 +448,16 @@ __device__ __forceinline__ void sk_edge_stream(KP p, CtlS* ctl, const PushEntry*
 
 // Appends the pushing nodes of one wave-step to the next level's push list (push_alloc of gfpush_kernels.hpp) and leaves
 // cnext * share -- what every edge of the entry adds to its target's reserve (graph.h:90) -- at the pusher's number in the row.
+// n_push / n_edges (wave-uniform) take the step's pushers and their edges: the statistics fall out of the ballot and the scan
+// that are computed anyway (three wave reductions per SCAN call otherwise).
 __device__ __forceinline__ void sk_push_alloc(KP p, CtlS* ctl, LevelCtr* nx, PushEntry* push, u32* bt_g, double* arch, u32 pu_next, double cnext,
-                                              u32 len, u32 start, double share, int lane, u32* bt_l, u32 bt_l_cap)
+                                              u32 len, u32 start, double share, int lane, u32* bt_l, u32 bt_l_cap, u32& n_push, u32& n_edges)
 {
     const u64 M = __ballot(len != 0);
     if (M == 0) return;                                                       // wave-uniform: nobody pushes
     const u32 incl = wave_incl_scan_dpp(len);
     const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    n_push += (u32)__popcll(M); n_edges += tot;
     u64 base = 0;
     if (lane == 0)
         base = __hip_atomic_fetch_add(&nx->alloc, ((u64)tot << 32) | (u64)(u32)__popcll(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -655,7 +658,7 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
                 k = lkeys[wb + idx]; r = lvals[wb + idx];
                 lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
                 deg = (u32)k >> p.deg_shift;
-                if (deg == p.deg_sat) { deg = sk_degree(p, (u32)k); ++st_deg; }           // graph.h:43-45 (a saturated degree field: one word of unit_info)
+                if (deg == p.deg_sat) deg = sk_degree(p, (u32)k);                         // graph.h:43-45 (a saturated degree field: one word of unit_info)
             }
             double share = 0.0; u32 len = 0;
             if (want) {
@@ -663,15 +666,16 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
                     __hip_atomic_fetch_add(&nx->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (r >= p.rmax * (double)deg) {                               // graph.h:94
-                    ++st_push; st_edges += deg;
+                    // (a push always has a share > 0 here: r >= rmax * deg with rmax * 2^31 >= 64, so pushes and pushed edges are
+                    //  the entries and edges sk_push_alloc hands out)
                     const double sh = r / (double)deg;                                // graph.h:95
                     if (sh != 0.0) { share = sh; len = deg; }
                 }
             }
-            sk_push_alloc(p, ctl, nx, push, bt_g, w.arch, pu_next, cnext, len, ((u32)k & p.node_mask) << kSkUnitShift, share, lane, w.bt_l, w.bt_l_cap);
+            st_deg += (u32)__popcll(__ballot(want && ((u32)k >> p.deg_shift) == p.deg_sat));
+            sk_push_alloc(p, ctl, nx, push, bt_g, w.arch, pu_next, cnext, len, ((u32)k & p.node_mask) << kSkUnitShift, share, lane, w.bt_l, w.bt_l_cap, st_push, st_edges);
         }
         SKT2(ctl, 7);
-        st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
         if (lane == 0) {
             __hip_atomic_fetch_add(&nx->n_rec, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // nodes the exact table held
             if (st_deg) zstat(ctl, zDeg, st_deg);
@@ -778,19 +782,18 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
         double share = 0.0; u32 len = 0;
         if (cand) {
             u32 deg = dq;
-            if (dq == p.deg_sat) { deg = sk_degree(p, (u32)k); ++st_deg; }                            // graph.h:43-45
+            if (dq == p.deg_sat) deg = sk_degree(p, (u32)k);                                          // graph.h:43-45
             if (deg == 0) {                                                                           // graph.h:91-93
                 __hip_atomic_fetch_add(&nx->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (r >= p.rmax * (double)deg) {                                                   // graph.h:94
-                ++st_push; st_edges += deg;
                 const double s_ = r / (double)deg;                                                    // graph.h:95
                 if (s_ != 0.0) { share = s_; len = deg; }
             }
         }
-        sk_push_alloc(p, ctl, nx, push_nxt, bt_nxt, w.arch, pu_next, cnext, len, ((u32)k & p.node_mask) << kSkUnitShift, share, (int)lane, w.bt_l, w.bt_l_cap);
+        st_deg += (u32)__popcll(__ballot(cand && dq == p.deg_sat));
+        sk_push_alloc(p, ctl, nx, push_nxt, bt_nxt, w.arch, pu_next, cnext, len, ((u32)k & p.node_mask) << kSkUnitShift, share, (int)lane, w.bt_l, w.bt_l_cap, st_push, st_edges);
     }
-    st_push = wave_sum32(st_push); st_edges = wave_sum32(st_edges); st_deg = wave_sum32(st_deg);
     if (lane == 0) {
         nx->n_rec = n_list;
         if (st_deg) zstat(ctl, zDeg, st_deg);

@@ -233,6 +233,7 @@ __device__ __forceinline__ u32 sk_degree(KP p, u32 key) {
 // when the group is consumed: a conditional load merges control flow between issue and use, and the compiler then waits for ALL
 // loads in flight.)  NT: the records are not needed again (TOP-K's sweep) -- the loads carry the non-temporal hint, so the lines
 // leave the L2 first.
+template <bool V> struct SkAllValid { static constexpr bool value = V; };
 template <int BLOCK, bool NT = false, class F>
 __device__ __forceinline__ void log_groups(const int* lk, const unsigned short* lp, u32 first, u32 end, F f)
 {
@@ -253,7 +254,10 @@ __device__ __forceinline__ void log_groups(const int* lk, const unsigned short* 
     for (;;) {
         int k[4]; u32 pu[4];
         const u32 i0 = g + 4u * lane;
-        if (g >= first && g + 256u <= end) {                              // (wave-uniform) a group inside the segment: nothing to mask
+        // (wave-uniform) a group inside the segment has nothing to mask -- and its consumer nothing to guard: every record holds a
+        //  key >= 0.  f(key[4], pusher[4], all_valid) is compiled for both cases.
+        const bool whole = g >= first && g + 256u <= end;
+        if (whole) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { k[q] = kn[q]; pu[q] = (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; }
         } else {
@@ -267,7 +271,7 @@ __device__ __forceinline__ void log_groups(const int* lk, const unsigned short* 
         g += kStride;
         const bool more = g < end;                                    // wave-uniform
         if (more) load(g);
-        f(k, pu);
+        if (whole) f(k, pu, SkAllValid<true>()); else f(k, pu, SkAllValid<false>());
         if (!more) break;
     }
 }
@@ -290,9 +294,10 @@ __device__ __forceinline__ void log_groups2_nt(const int* lk, const unsigned sho
         const u32 i = min(g0 + 4u * lane, last_chunk);
         kn = __builtin_nontemporal_load((const i4*)&lk[i]); pn = __builtin_nontemporal_load((const u2*)&lp[i]);
     };
-    auto consume = [&](u32 g0, const i4& kn, const u2& pn, int (&k)[4], u32 (&pu)[4]) {
+    auto consume = [&](u32 g0, const i4& kn, const u2& pn, int (&k)[4], u32 (&pu)[4]) -> bool {
         const u32 i0 = g0 + 4u * lane;
-        if (g0 + 256u <= end) {                                           // (wave-uniform) every group but the log's last: nothing to mask
+        const bool whole = g0 + 256u <= end;
+        if (whole) {                                                      // (wave-uniform) every group but the log's last: nothing to mask
 #pragma unroll
             for (int q = 0; q < 4; ++q) { k[q] = kn[q]; pu[q] = (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; }
         } else {
@@ -303,20 +308,23 @@ __device__ __forceinline__ void log_groups2_nt(const int* lk, const unsigned sho
                 pu[q] = in ? (pn[q >> 1] >> (16 * (q & 1))) & 0xFFFFu : 0u;
             }
         }
+        return whole;
     };
     load(g, ka, pa);
     kb = ka; pb = pa;
     if (g + kStride < end) load(g + kStride, kb, pb);
     for (;;) {
         int k[4]; u32 pu[4];
+        // (the consumer is compiled once here, guards included: a second copy of TOP-K's insert loop makes that function save nine
+        //  more callee-saved registers to scratch)
         consume(g, ka, pa, k, pu);
         if (g + 2u * kStride < end) load(g + 2u * kStride, ka, pa);      // (wave-uniform)
-        f(k, pu);
+        f(k, pu, SkAllValid<false>());
         g += kStride;
         if (g >= end) break;
         consume(g, kb, pb, k, pu);
         if (g + 2u * kStride < end) load(g + 2u * kStride, kb, pb);
-        f(k, pu);
+        f(k, pu, SkAllValid<false>());
         g += kStride;
         if (g >= end) break;
     }
@@ -543,21 +551,19 @@ __device__ GP_PHASE_NOINLINE void phase_sk_filter(u32 lds0, u32 seg_base, u32 n,
     const double* S = w.xvals + capx;
     u32 n_cand = 0;
     SKT2(w.ctl, 0);
-    log_groups<BLOCK>(w.log_key, w.log_pu, seg_base, seg_base + n, [&](const int (&k)[4], const u32 (&pu)[4]) {
+    log_groups<BLOCK>(w.log_key, w.log_pu, seg_base, seg_base + n, [&](const int (&k)[4], const u32 (&pu)[4], auto all_valid) {
+        constexpr bool kAll = decltype(all_valid)::value;                             // every record of the group is one: no guards
         u32 cell[4]; double s[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                                                 // eight lookups in flight
-            cell[q] = w.U[sk_cell((u32)max(k[q], 0)) >> w.shU];
-            s[q] = S[k[q] >= 0 ? pu[q] - pu_base : 0u];
+            cell[q] = w.U[sk_cell(kAll ? (u32)k[q] : (u32)max(k[q], 0)) >> w.shU];
+            s[q] = S[kAll || k[q] >= 0 ? pu[q] - pu_base : 0u];
         }
         int kc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            bool cand = k[q] >= 0;
-            if (cand) {
-                const u32 dq = (u32)k[q] >> dshift;                                   // min(deg, deg_sat); 0: dangling, always exact
-                cand = (float)cell[q] >= (float)dq * thr;                             // thr = rmax * 2^31 * (1 - 2^-10), rounded down
-            }
+            const u32 dq = (u32)k[q] >> dshift;                                       // min(deg, deg_sat); 0: dangling, always exact
+            const bool cand = (kAll || k[q] >= 0) && (float)cell[q] >= (float)dq * thr;   // thr = rmax * 2^31 * (1 - 2^-10), rounded down
             n_cand += (u32)__popcll(__ballot(cand));
             kc[q] = cand ? k[q] : -1;
         }
@@ -1062,16 +1068,17 @@ __device__ GP_PHASE_NOINLINE void phase_sk_topk(u32 lds0, u32 row_lo, u32 row_hi
                 }
                 table_ready = false;
                 if (mine.key != kEmpty && !sk_res_add_lds(t.akeys, t.avals, t.CA, mine.key, __longlong_as_double((long long)mine.bits))) ctl->ovf = 1;
-                auto tabled = [&](const int (&k)[4], const u32 (&pu)[4]) {
+                auto tabled = [&](const int (&k)[4], const u32 (&pu)[4], auto all_valid) {
+                    constexpr bool kAll = decltype(all_valid)::value;                 // every record of the group is one: no guards
                     u32 cell[4]; double cv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {                                     // eight lookups in flight
-                        cell[q] = t.R[sk_cell((u32)max(k[q], 0)) >> t.shR];
+                        cell[q] = t.R[sk_cell(kAll ? (u32)k[q] : (u32)max(k[q], 0)) >> t.shR];
                         cv[q] = TG ? w.arch[pu[q]] : t.T[pu[q]];
                     }
                     int kh[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) kh[q] = k[q] >= 0 && cv[q] != 0.0 && cell[q] >= t_c ? k[q] : -1;
+                    for (int q = 0; q < 4; ++q) kh[q] = (kAll || k[q] >= 0) && cv[q] != 0.0 && cell[q] >= t_c ? k[q] : -1;
                     insert_windows4_asm<true>(t.akeys, t.avals, t.CA, &ctl->ovf, kh, cv, P, part);               // graph.h:90 / :109
                 };
 #if GP_SK_SWEEP_DEPTH == 2

@@ -61,6 +61,19 @@ class GpStats(ctypes.Structure):
 _LIB = None
 
 
+def _optional(L, name, argtypes):
+    """Declare an entry point an older build (GRANDPLUS_LIB=... for an A/B run) may lack: calling it there raises a clear error."""
+    try:
+        f = getattr(L, name)
+    except AttributeError:
+        def missing(*_a, **_k):
+            raise RuntimeError(f"{LIB_PATH} does not export {name} (an older build?): rebuild the library")
+        setattr(L, name, missing)
+        return
+    f.restype = ctypes.c_int
+    f.argtypes = argtypes
+
+
 def lib():
     """Load libgrandplus.so (once).  Raises RuntimeError if it has not been built."""
     global _LIB
@@ -91,11 +104,7 @@ def lib():
                                   ctypes.POINTER(vp)]
     L.gp_graph_create_multi.restype = ctypes.c_int
     L.gp_graph_create_multi.argtypes = [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(vp)]
-    try:
-        L.gp_graph_create_multi_on.restype = ctypes.c_int
-        L.gp_graph_create_multi_on.argtypes = [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
-    except AttributeError:                  # (an older build loaded through GRANDPLUS_LIB for an A/B run)
-        pass
+    _optional(L, "gp_graph_create_multi_on", [i32p, ctypes.c_int64, i32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)])
     L.gp_graph_num_gpus.restype = ctypes.c_int
     L.gp_graph_num_gpus.argtypes = [vp]
     L.gp_graph_destroy.restype = None
@@ -123,26 +132,20 @@ def lib():
     L.gp_random_prop_coo.restype = ctypes.c_int
     L.gp_random_prop_coo.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, ctypes.c_int64,
                                      ctypes.c_float, ctypes.c_int, ctypes.c_uint64, vp, vp, vp]
-    try:
-        L.gp_seed_positions.restype = ctypes.c_int
-        L.gp_seed_positions.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int64, vp, vp, vp]
-        L.gp_batch_positions.restype = ctypes.c_int
-        L.gp_batch_positions.argtypes = [ctypes.c_int, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, vp]
-    except AttributeError:                  # (an older build loaded through GRANDPLUS_LIB for an A/B run)
-        pass
+    _optional(L, "gp_seed_positions", [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int64, vp, vp, vp])
+    _optional(L, "gp_batch_positions", [ctypes.c_int, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, vp])
     L.gp_propagate_features.restype = ctypes.c_int
     L.gp_propagate_features.argtypes = [vp, vp, ctypes.c_int32, vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, vp]
     L.gp_internal_diag_counters.restype = ctypes.c_int
     L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
-    try:
-        L.gp_internal_graph_acsr.restype = ctypes.c_int
-        L.gp_internal_graph_acsr.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)]
-    except AttributeError:                  # (an older build loaded through GRANDPLUS_LIB for an A/B run: tests/test_host_logic.py checks the product's exports)
-        pass
+    _optional(L, "gp_internal_graph_acsr", [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)])
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
-    if L.gp_abi_version() not in (3, 4):      # (3: an older build loaded through GRANDPLUS_LIB for an A/B run; its gp_stats is a prefix of this one)
-        raise RuntimeError("libgrandplus.so ABI version mismatch")
+    # (ABI 3 is accepted only for an older build named explicitly through GRANDPLUS_LIB for an A/B run: its gp_stats is a prefix of
+    #  this one, and the entry points it lacks raise a clear error where they are called -- _optional)
+    abi = L.gp_abi_version()
+    if abi != 4 and not (abi == 3 and os.environ.get("GRANDPLUS_LIB")):
+        raise RuntimeError(f"libgrandplus.so ABI version {abi}, this package needs 4: rebuild (python -c 'import __graft_entry__ as g; g.build()')")
     _LIB = L
     return L
 

@@ -80,7 +80,7 @@ typedef struct gp_stats {
     int64_t sketch_second_sweeps;    /* rows whose top-K needed a second sweep over their log                          */
     /* ABI 4: the measured choice.  With nothing forced (options kernel / block_threads / lds_bytes all 0, "measure_choice" 1) the
      * first call of >= 32 768 rows of a recipe (rmax, n_coef, K) on a graph times its candidates -- they are exact and
-     * interchangeable -- on its first 16 384 rows, and every later call of that recipe runs what the rmax / graph-size thresholds
+     * interchangeable -- on its first 16 384 rows (into scratch outputs), and every later call of that recipe, of any size, runs what the rmax / graph-size thresholds
      * pick unless another candidate was more than 5 % faster: [0] the general kernel in the launch shape the thresholds pick,
      * [1] the sketch kernel, [2] the general kernel in the other shape.
      * Milliseconds of those timing runs behind the LAST call's decision (0 = not a candidate / nothing was measured for it);
@@ -161,6 +161,10 @@ int gp_gfpush(gp_graph* g,
  * the multi-GPU driver use (inputs already resident in HBM, RCCL all-gather consumes the
  * outputs on device).  d_row/d_col/d_val are [S*K]; slots i >= d_filled[it] of a row are left
  * untouched.  d_filled is int32[S] (may be NULL).  coef is a HOST array (n_coef doubles).
+ * ONE-OFF SYNCHRONOUS CALLS: the first call that takes the sketch kernel builds the self-addressed CSR (one stream
+ * synchronisation), and the first call of >= 32 768 rows of a recipe times its candidates first (gp_stats.choice_ms: six
+ * launches of 16 384 rows into scratch output buffers of the library's own -- never into d_row/d_col/d_val -- and two stream
+ * synchronisations).  Every other call only enqueues.  Option "measure_choice" = 0 avoids the second.
  */
 int gp_gfpush_device(gp_graph* g,
                      const int32_t* d_seeds, int64_t n_seeds,

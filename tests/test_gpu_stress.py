@@ -124,7 +124,8 @@ def test_calibration_candidate_that_cannot_run_is_not_the_callers_error():
     indptr, indices = synth.shape_csr("tiny")                  # (2 000 nodes: every row walks the whole graph; slabs are sized from nnz)
     r = RECIPES[("mag", "ppr")]
     K, S = r.top_k, 32768
-    seeds = synth.seeds(len(indptr) - 1, S)
+    n = len(indptr) - 1
+    seeds = np.resize(synth.seeds(n, n), S)                    # (every node, cycled: duplicate seeds give duplicate rows)
     ref = Graph(indptr, indices, 0)
     ref.set_option("kernel", 1)
     row0 = np.zeros(S * K, np.int32); col0 = np.zeros(S * K, np.int32); val0 = np.zeros(S * K)

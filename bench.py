@@ -56,6 +56,10 @@ WORKLOADS = {
 }
 
 
+# S of the reference's ONE call per process (model.py:244-248 with the shipped --unlabel_num)
+REFERENCE_S = {"mag": 10400, "amazon2m": 12350, "reddit": 12050, "pubmed": 1559, "cora": 1639, "small": 2048}
+
+
 def kernel_source_sha16() -> str:
     """Identity of the GFPush kernel sources: profiles/*_pmc_summary.json carries the hash it was measured on."""
     h = hashlib.sha256()
@@ -119,6 +123,85 @@ def cpu_baseline(indptr, indices, seeds, recipe, budget_s: float = 12.0):
         out.update({"value": refv, "cores": 40, "kind": "reference",
                     "sample": f"{n} seeds of the same workload, reference precompute/propagation.cpp compiled as oracle/_ref, 40 OpenMP threads as shipped (graph.h:41) on {cores} cores, best of 3"})
     return out
+
+
+def cold_call_child(workload: str) -> int:
+    """The drop-in's real call pattern (model.py:251,268): a FRESH process makes ONE constructor and ONE gfpush_omp
+    call of the reference's own S through the pybind11 module, wall-clock -- HIP runtime start, CSR upload, device-side
+    validation, the self-addressed copy, workspace and pinned slabs, code upload, kernel -- and, beside it, the reference
+    (oracle/_ref, 40 OpenMP threads as shipped) making the same two calls on this box's cores.  Prints one JSON line."""
+    from grand_plus_amd import RECIPES, _native
+    from precompute import propagation                       # the drop-in module, same import path as model.py:9
+    source, rkey, _ = WORKLOADS[workload]
+    recipe = RECIPES[rkey]
+    coef, K = recipe.coef(), recipe.top_k
+    indptr, indices = load_graph(source, os.cpu_count() or 8)
+    n_nodes = len(indptr) - 1
+    S = min(REFERENCE_S.get(workload, 10000), 4 * n_nodes)
+    node_idx = make_seeds(source, n_nodes, S).astype(np.int64)           # (the shipped caller passes int64: model.py:244-248)
+    out = {"S": S, "K": K, "what": "fresh process: propagation.Graph(indptr, indices, 0) + ONE gfpush_omp of the reference's own S, wall-clock"}
+
+    def one_call(g):
+        row = np.zeros(S * K, np.int32); col = np.zeros(S * K, np.int32); val = np.zeros(S * K, np.float64)     # model.py:252-254
+        t = time.perf_counter()
+        g.gfpush_omp(node_idx, row, col, val, coef, recipe.rmax, K)
+        return time.perf_counter() - t, (row, col, val)
+
+    t0 = time.perf_counter()
+    n_dev = _native.lib().gp_device_count()                  # the first HIP call of the process: the runtime starts here
+    t_init = time.perf_counter() - t0
+    if n_dev <= 0:
+        print(json.dumps({"error": "no HIP device"}), flush=True)
+        return 3
+    t0 = time.perf_counter()
+    g = propagation.Graph(indptr, indices, 0)
+    t_ctor = time.perf_counter() - t0
+    import ctypes
+    parts = (ctypes.c_double * 5)()
+    try:
+        _native.lib().gp_internal_create_ms(parts)
+    except Exception:
+        pass
+    t_call, got = one_call(g)
+    t_call2, _ = one_call(g)
+    out.update({"gpu_s": round(t_init + t_ctor + t_call, 4), "hip_runtime_start_s": round(t_init, 4), "ctor_s": round(t_ctor, 4),
+                "ctor_ms_parts": {k: round(float(v), 2) for k, v in zip(("device", "alloc", "upload", "validate", "objects"), list(parts))},
+                "first_call_s": round(t_call, 4), "second_call_s": round(t_call2, 4)})
+    del g
+    from oracle import pyoracle
+    ref = pyoracle.load_reference_module()
+    if ref is not None:
+        t0 = time.perf_counter()
+        rg = ref.Graph(indptr, indices, 0)
+        rt_ctor = time.perf_counter() - t0
+        rt_call, exp = one_call(rg)
+        out.update({"cpu_reference_s": round(rt_ctor + rt_call, 4), "cpu_reference_ctor_s": round(rt_ctor, 4), "cpu_reference_call_s": round(rt_call, 4),
+                    "cpu_reference": f"oracle/_ref (the reference compiled as it lies), 40 OpenMP threads as shipped (graph.h:41) on {os.cpu_count()} cores",
+                    "speedup": round((rt_ctor + rt_call) / (t_init + t_ctor + t_call), 2)})
+        from grand_plus_amd.parity import compare_rows
+        rep = compare_rows(node_idx, K, got, exp)
+        out["rows_equal_the_references"] = bool(rep.ok)
+    else:
+        threads = min(40, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        pyoracle.gfpush(indptr, indices, node_idx, coef, recipe.rmax, K, threads=threads)
+        out.update({"cpu_reference_s": round(time.perf_counter() - t0, 4), "cpu_reference": f"oracle/gfpush_oracle.cpp (port), {threads} threads", })
+        out["speedup"] = round(out["cpu_reference_s"] / out["gpu_s"], 2)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def cold_call(workload: str):
+    """Runs cold_call_child in a child process.  Called BEFORE this process touches HIP (the child starts its own runtime)."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-call-child", "--workload", workload],
+                           capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if lines:
+            return json.loads(lines[-1])
+        return {"error": f"child exited with code {r.returncode}", "stderr": r.stderr[-500:]}
+    except Exception as e:                                   # never lose the headline line to a side measurement
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def next_rows(graph, packed, per, K, n_nodes, nnz, dev):
@@ -225,6 +308,8 @@ def parse_args():
     ap.add_argument("--force-global", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="gp_set_option on the graph (A/B runs), e.g. --opt seedrow=0")
     ap.add_argument("--diag-flags", type=int, default=0, help="GRANDPLUS_DIAG=1 builds only: bit 0 skips TOP-K (instruction attribution)")
+    ap.add_argument("--no-cold-call", action="store_true", help="skip the cold_call block (a fresh child process: constructor + one reference-sized call)")
+    ap.add_argument("--cold-call-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -256,7 +341,7 @@ class CudaPlatform:
         torch.cuda.synchronize(dev)
 
 
-def run_rank(args, platform=CudaPlatform) -> int:
+def run_rank(args, platform=CudaPlatform, cold=None) -> int:
     import torch
     import torch.distributed as dist
     from grand_plus_amd import RECIPES, algorithmic_bytes
@@ -492,6 +577,8 @@ def run_rank(args, platform=CudaPlatform) -> int:
             line["host_api"] = {"rows_per_s": round(per / med, 1), "ms_per_call": round(med * 1e3, 3), "rows_per_call": per,
                                 "first_call_ms": round(ts[0] * 1e3, 3),
                                 "what": "Graph.gfpush_omp (gp_gfpush): int64 seeds on the host -> numpy row/col/value filled in place, median of 3 calls after one warm-up"}
+        if cold is not None:
+            line["cold_call"] = cold
         if world == 1 and not args.no_next_rows:
             line["next_rows"] = next_rows(graph, packed, per, K, n_nodes, len(indices), dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -512,9 +599,14 @@ def run_rank(args, platform=CudaPlatform) -> int:
 
 def main():
     args = parse_args()
+    if args.cold_call_child:
+        sys.exit(cold_call_child(args.workload))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
-    sys.exit(run_rank(args))
+    cold = None
+    if "WORLD_SIZE" not in os.environ and args.gpus == 1 and not args.no_cold_call:
+        cold = cold_call(args.workload)                      # (a child process, started before this one touches HIP)
+    sys.exit(run_rank(args, cold=cold))
 
 
 if __name__ == "__main__":

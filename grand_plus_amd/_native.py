@@ -28,7 +28,7 @@ EXPORTS = (
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
     "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_graph_acsr", "gp_graph_create_multi_on",
-    "gp_seed_positions", "gp_batch_positions",
+    "gp_seed_positions", "gp_batch_positions", "gp_internal_create_ms",
 )
 
 
@@ -139,6 +139,11 @@ def lib():
     L.gp_internal_diag_counters.restype = ctypes.c_int
     L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     _optional(L, "gp_internal_graph_acsr", [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)])
+    try:
+        L.gp_internal_create_ms.restype = None
+        L.gp_internal_create_ms.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    except AttributeError:
+        pass
     L.gp_set_option.restype = ctypes.c_int
     L.gp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     # (ABI 3 is accepted only for an older build named explicitly through GRANDPLUS_LIB for an A/B run: its gp_stats is a prefix of

@@ -298,6 +298,9 @@ int gp_internal_multi_plan(int64_t n_seeds, int K, int n_parts, int64_t min_rows
 
 /* internal: lets the second translation unit report through gp_last_error (not for callers) */
 void gp_internal_set_error(int status, const char* where, const char* detail);
+/* Milliseconds the calling thread's last gp_graph_create spent: [0] HIP runtime + device, [1] allocations, [2] upload, [3] validation on
+ * the device, [4] per-graph objects (bench.py's cold_call block). */
+void gp_internal_create_ms(double* out5);
 
 #ifdef __cplusplus
 }

@@ -191,6 +191,32 @@ def test_dtype_guard_and_untouched_slots():
     g.gfpush_omp(np.array([], np.int64), ok_r, ok_c, ok_v, KAT_COEF, 0.0, 4)   # empty seed list is a no-op
 
 
+def test_column_ids_are_validated_on_the_device():
+    """graph.h:32-47 trusts its input; gp_graph_create checks indptr on the host and the column ids with one kernel behind the
+    upload (round 6): out of range -> ValueError from both constructors; a row that is not strictly increasing is legal
+    (graph.h:96-99 adds the share once per stored entry) and only loses level 1's shortcut -- its rows equal the oracle's."""
+    from grand_plus_amd import Graph
+    from precompute import propagation
+    ok_ptr = np.array([0, 1, 2], np.int32)
+    for ctor in (Graph, propagation.Graph):
+        with pytest.raises(ValueError, match="column id"):
+            ctor(ok_ptr, np.array([0, 9], np.int32), 0)
+        with pytest.raises(ValueError, match="column id"):
+            ctor(ok_ptr, np.array([-1, 1], np.int32), 0)
+    big_ptr = np.arange(0, 6 * 100001, 6, dtype=np.int32)                            # a graph large enough for the staged upload path to matter little: one bad word far inside
+    big_idx = (np.arange(6 * 100000, dtype=np.int64) * 7919 % 100000).astype(np.int32)
+    bad = big_idx.copy(); bad[345678] = 100000
+    with pytest.raises(ValueError, match="column id"):
+        Graph(big_ptr, bad, 0)
+    # repeated and unsorted columns inside a row
+    indptr = np.array([0, 3, 5, 6], np.int32); indices = np.array([2, 1, 1, 0, 0, 2], np.int32)
+    coef = KAT_COEF
+    got, st = _run_gpu(indptr, indices, [0, 1, 2], coef, 0.0, 3)
+    exp, ost = _oracle(indptr, indices, [0, 1, 2], coef, 0.0, 3)
+    _assert_parity([0, 1, 2], 3, got, exp, label="unsorted rows")
+    assert (st["pushes"], st["edges"], st["filled"]) == (ost["pushes"], ost["edges"], ost["filled"])
+
+
 def test_single_mode_zero_reserves_are_not_written():
     """coef = e_L: nodes seen only before the last level have reserve exactly 0 and must be filtered
     by v > 0 (graph.h:121), leaving fewer than K filled slots."""

@@ -18,6 +18,6 @@ PMC_SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_H
         "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS")
 for grp in "${PMC_SETS[@]}"; do
   i=$((i+1))
-  timeout -k 5 100 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py --workload $W --prewarm 0 --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows --opt measure_choice=0 "$@" > $OUT/g$i.log 2>&1
+  timeout -k 5 100 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py --workload $W --prewarm 0 --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows --no-cold-call --opt measure_choice=0 "$@" > $OUT/g$i.log 2>&1
   echo "group $i ($grp): rc=$?"
 done

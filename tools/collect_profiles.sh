@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 export GRANDPLUS_SYNTH_CACHE=${GRANDPLUS_SYNTH_CACHE:-/dev/shm/gp_synth}
 mkdir -p $OUT
 # 1. kernel trace of the default bench line (MAG shape)
-timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --prewarm 0 --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows --opt measure_choice=0 > $OUT/trace.log 2>&1
+timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --prewarm 0 --steps 5 --warmup 2 --no-cpu-baseline --no-host-api --no-next-rows --no-cold-call --opt measure_choice=0 > $OUT/trace.log 2>&1
 cp $(ls -t $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 # 2. PMC passes: all counter groups for the headline workload, the memory-side and instruction groups for the other four
 #    (every bench line then carries counter traffic -- VERDICT r4 #4)

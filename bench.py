@@ -381,6 +381,13 @@ def run_rank(args, platform=CudaPlatform, cold=None) -> int:
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     try:
+        from grand_plus_amd import _native
+        _native.lib().gp_device_count()                              # the first HIP call of the process: the runtime starts here, not inside the constructor's clock
+    except Exception:
+        pass
+    t_runtime = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    try:
         graph = Graph(indptr, indices, 0, device=local_rank)        # no GPU => GP_ERR_NO_DEVICE (there is no CPU path)
     except RuntimeError as e:
         print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
@@ -529,7 +536,7 @@ def run_rank(args, platform=CudaPlatform, cold=None) -> int:
                        "sketch_second_rounds_per_row": round(stats.get("sketch_second_sweeps", 0) / max(stats["rows"], 1), 4),
                        "max_level_edges": stats["max_level_edges"],
                        "max_log_records": stats["max_log_records"],
-                       "graph_gen_s": round(t_gen, 2), "csr_upload_s": round(t_upload, 3)},
+                       "graph_gen_s": round(t_gen, 2), "csr_upload_s": round(t_upload, 3), "hip_runtime_start_s": round(t_runtime, 3)},
         }
         # HBM-side traffic per launch: measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes of this
         # same command, tools/collect_pmc.sh) and committed under profiles/ together with the hash of the kernel

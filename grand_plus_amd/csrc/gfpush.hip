@@ -102,7 +102,7 @@ struct Workspace {
 struct gp_graph {
     int device = 0;
     int64_t n_nodes = 0, nnz = 0;
-    int* d_indptr = nullptr; int* d_indices = nullptr;
+    int* d_indptr = nullptr; int* d_indices = nullptr; void* d_csr_block = nullptr;   // (d_csr_block: both arrays live in one allocation -- gp_graph_create; a replica allocates them one by one)
     int deg_shift = 31; uint32_t node_mask = 0x7FFFFFFFu, deg_sat = 0;   // packed column ids (see pack_degree_kernel)
     bool packed = false; int max_degree_bits = 31;                        // packing happens at the first gfpush call
     // self-addressed CSR of the sketch kernel (ensure_acsr; built at the first call that kernel takes): rows at 128-byte units,
@@ -154,7 +154,7 @@ struct gp_graph {
     // mirror: the rows come back with ONE D2H copy (the layout grand_plus_amd/sharded.py all-gathers)
     int* d_seeds = nullptr; int64_t seeds_cap = 0;
     char* d_out = nullptr; size_t out_bytes = 0;
-    char* h_slab[2] = {nullptr, nullptr}; bool h_slab_clean[2] = {false, false}; int h_slab_next = 0; std::vector<unsigned char> h_done;     // gp_gfpush: two pinned output slabs, used alternately
+    char* h_slab[2] = {nullptr, nullptr}; bool h_slab_clean[2] = {false, false}; int h_slab_next = 0; std::vector<unsigned char> h_done, h_rowbuf;     // gp_gfpush: two pinned output slabs, used alternately
 };
 
 namespace {
@@ -821,11 +821,12 @@ int gp_graph_create(const int32_t* indptr, int64_t n_nodes, const int32_t* indic
     g->num_cus = prop.multiProcessorCount;
     auto cleanup = [&](int status) { gp_graph_destroy(g); return status; };
     u32* d_flags = nullptr;
-    if (hipMalloc(&g->d_indptr, sizeof(int) * (size_t)(n_nodes + 1)) != hipSuccess ||
-        hipMalloc(&g->d_indices, sizeof(int) * (size_t)(nnz + 1)) != hipSuccess ||      // + the sentinel word indices[nnz] = -1
-        hipMalloc(&d_flags, sizeof(u32) * 2) != hipSuccess)
-        return cleanup(fail(GP_ERR_NOMEM, "hipMalloc of the CSR (%lld nodes, %lld nnz) failed", (long long)n_nodes, (long long)nnz));
-    struct FlagGuard { u32* p; ~FlagGuard() { if (p) (void)hipFree(p); } } flag_guard{d_flags};
+    {   // ONE allocation: [indices + the sentinel word indices[nnz] = -1 | indptr | the validation flags] (an allocation call costs tens of ms)
+        const size_t b_idx = (sizeof(int) * (size_t)(nnz + 1) + 255) & ~(size_t)255, b_ptr = (sizeof(int) * (size_t)(n_nodes + 1) + 255) & ~(size_t)255;
+        if (hipMalloc(&g->d_csr_block, b_idx + b_ptr + 256) != hipSuccess)
+            return cleanup(fail(GP_ERR_NOMEM, "hipMalloc of the CSR (%lld nodes, %lld nnz) failed", (long long)n_nodes, (long long)nnz));
+        g->d_indices = (int*)g->d_csr_block; g->d_indptr = (int*)((char*)g->d_csr_block + b_idx); d_flags = (u32*)((char*)g->d_csr_block + b_idx + b_ptr);
+    }
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess)
         return cleanup(fail(GP_ERR_HIP, "creating per-graph HIP objects failed"));
     g_create_ms[1] = ms_since(t0); t0 = clk::now();              // allocations
@@ -874,8 +875,11 @@ void gp_graph_destroy(gp_graph* g) {
     (void)hipSetDevice(g->device);
     if (g->launched) (void)hipStreamSynchronize(g->last_stream);
     free_workspace(g->ws);
-    if (g->d_indptr) (void)hipFree(g->d_indptr);
-    if (g->d_indices) (void)hipFree(g->d_indices);
+    if (g->d_csr_block) (void)hipFree(g->d_csr_block);
+    else {
+        if (g->d_indptr) (void)hipFree(g->d_indptr);
+        if (g->d_indices) (void)hipFree(g->d_indices);
+    }
     if (g->d_acsr) (void)hipFree(g->d_acsr);
     if (g->d_node_pos) (void)hipFree(g->d_node_pos);
     if (g->d_unit_info) (void)hipFree(g->d_unit_info);
@@ -1397,6 +1401,11 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
     int64_t first_open = 0, n_merged = 0;
     std::vector<unsigned char>& done = g->h_done;          // (kept with the graph: no allocation per call)
     done.assign((size_t)n_seeds, 0);
+    // (a row's three segments are first copied to a scratch row of this call -- plain memcpy -- and judged THERE with loops the
+    //  compiler vectorises: 96 volatile loads per row were most of this thread's CPU time)
+    std::vector<unsigned char>& rowbuf = g->h_rowbuf;
+    rowbuf.resize(16 * (size_t)K);
+    int* const b_row = (int*)rowbuf.data(); int* const b_col = b_row + K; uint64_t* const b_val = (uint64_t*)(rowbuf.data() + 8 * (size_t)K);
     auto sweep = [&]() {                       // merges every row that has fully arrived since the last sweep
         bool prefix = true;
         for (int64_t it = first_open; it < n_seeds; ++it) {
@@ -1404,14 +1413,17 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
             const int nf = h_filled[it];
             if (nf < 0 || nf > K) { prefix = false; continue; }
             const int64_t o = it * (int64_t)K;
-            bool here = true;
-            for (int i = 0; i < nf && here; ++i) here = h_row[o + i] >= 0 && h_col[o + i] >= 0 && h_val[o + i] != ~0ull;
-            if (!here) { prefix = false; continue; }
-            std::atomic_thread_fence(std::memory_order_acquire);
             if (nf > 0) {
-                std::memcpy(row_idx + o, (const void*)(h_row + o), sizeof(int) * (size_t)nf);
-                std::memcpy(col_idx + o, (const void*)(h_col + o), sizeof(int) * (size_t)nf);
-                std::memcpy(value + o, (const void*)(h_val + o), sizeof(double) * (size_t)nf);
+                std::memcpy(b_row, (const void*)(h_row + o), sizeof(int) * (size_t)nf);
+                std::memcpy(b_col, (const void*)(h_col + o), sizeof(int) * (size_t)nf);
+                std::memcpy(b_val, (const void*)(h_val + o), sizeof(double) * (size_t)nf);
+                int lo = 0; uint64_t sent = 0;
+                for (int i = 0; i < nf; ++i) { lo |= b_row[i] | b_col[i]; sent |= (uint64_t)(b_val[i] == ~0ull); }     // (a sentinel word is -1: the sign bit of the OR says one is left)
+                if (lo < 0 || sent) { prefix = false; continue; }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                std::memcpy(row_idx + o, b_row, sizeof(int) * (size_t)nf);
+                std::memcpy(col_idx + o, b_col, sizeof(int) * (size_t)nf);
+                std::memcpy(value + o, b_val, sizeof(double) * (size_t)nf);
             }
             done[it] = 1; ++n_merged;
             if (prefix) first_open = it + 1;
@@ -1438,7 +1450,7 @@ int gp_gfpush(gp_graph* g, const int32_t* seeds, int64_t n_seeds,
         if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }        // gp_get_stats below reports it
         const int64_t before = n_merged;
         sweep();
-        if (n_merged - before < 64) std::this_thread::sleep_for(std::chrono::microseconds(n_merged == before ? 200 : 50));
+        if (n_merged - before < 256) std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
     if (resetter.t.joinable()) { resetter.t.join(); g->h_slab_clean[cur ^ 1] = true; }
     else if (reset_inline) { std::memset(idle, 0xFF, g->out_bytes); g->h_slab_clean[cur ^ 1] = true; }

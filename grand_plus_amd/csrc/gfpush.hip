@@ -930,7 +930,7 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
         if (value < 0 || value > 2) return fail(GP_ERR_INVALID_ARG, "kernel must be 0 (automatic), 1 (general) or 2 (sketch)");
         g->kernel = (int)value;
     } else if (k == "sk_block_threads") {
-        if (value != 0 && value != 512 && value != 768) return fail(GP_ERR_INVALID_ARG, "sk_block_threads must be 0, 512 or 768");
+        if (value != 0 && value != 512 && value != 768 && value != 1024) return fail(GP_ERR_INVALID_ARG, "sk_block_threads must be 0, 512, 768 or 1024");
         g->sk_block = (int)value;
     } else if (k == "sk_lg_mu" || k == "sk_lg_mr") {
         if (value != 0 && (value < 8 || value > 14)) return fail(GP_ERR_INVALID_ARG, "%s must be 0 or in [8, 14]", key);
@@ -1080,11 +1080,11 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
 #ifndef GP_DIAG
     if (use_sk) {
         sk_block = g->sk_block ? g->sk_block : 768;
-        sk_lds = sk_block == 512 ? kThreeLds : 80 * 1024;
-        sk_lg_mu = (u32)(g->sk_lg_mu ? g->sk_lg_mu : (sk_block == 512 ? 12 : 13));
+        sk_lds = sk_block == 512 ? kThreeLds : sk_block == 1024 ? 160 * 1024 : 80 * 1024;
+        sk_lg_mu = (u32)(g->sk_lg_mu ? g->sk_lg_mu : (sk_block == 512 ? 12 : sk_block == 1024 ? 14 : 13));
         // the reserve sketch resolves the K-th total when ~4K of its cells are heavy: 2 048 cells for K <= 32 (the MAG recipe: 1 024 / 4 096
         // cells +4 % / +5 % kernel time), 4 096 beyond (the Reddit recipe, K = 64: -5 %; the exact table pays for them with 680 slots)
-        sk_lg_mr = (u32)(g->sk_lg_mr ? g->sk_lg_mr : (K > 32 && sk_block == 768 ? 12 : 11));
+        sk_lg_mr = (u32)(g->sk_lg_mr ? g->sk_lg_mr : (K > 32 && sk_block >= 768 ? 12 : 11));
         const int64_t x_bytes = (int64_t)sk_lds - kCtlBytes - (4ll << sk_lg_mu) - (4ll << sk_lg_mr);
         sk_cx = x_bytes > 0 ? (u32)(x_bytes / 12) & ~3u : 0u;
         // the exact table, and the aggregation table TOP-K builds over the level sketch + exact table, need >= kMinCap slots
@@ -1096,7 +1096,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     }
     if (use_sk) {
         int per_cu = 1;
-        rc = sk_block == 512 ? resident_sk<512>(sk_lds + g->lds_pad, &per_cu) : resident_sk<768>(sk_lds + g->lds_pad, &per_cu);
+        rc = sk_block == 512 ? resident_sk<512>(sk_lds + g->lds_pad, &per_cu) : sk_block == 1024 ? resident_sk<1024>(sk_lds + g->lds_pad, &per_cu) : resident_sk<768>(sk_lds + g->lds_pad, &per_cu);
         if (rc) return rc;
         sk_wg = g->num_cus * per_cu;
         if (g->max_workgroups > 0) sk_wg = std::min(sk_wg, g->max_workgroups);
@@ -1252,7 +1252,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
         kp.indices = g->d_acsr; kp.nnz = (int)(g->n_units << 5);
         kp.deg_shift = g->a_shift; kp.node_mask = g->a_mask; kp.deg_sat = g->a_sat;
         kp.node_pos = g->d_node_pos; kp.unit_info = g->d_unit_info; kp.sk_hub_units = g->a_sat > 32u ? 1u : 0u;
-        rc = sk_block == 512 ? launch_sk<512>(kp, sk_wg, sk_lds + g->lds_pad, s) : launch_sk<768>(kp, sk_wg, sk_lds + g->lds_pad, s);
+        rc = sk_block == 512 ? launch_sk<512>(kp, sk_wg, sk_lds + g->lds_pad, s) : sk_block == 1024 ? launch_sk<1024>(kp, sk_wg, sk_lds + g->lds_pad, s) : launch_sk<768>(kp, sk_wg, sk_lds + g->lds_pad, s);
         if (rc) return rc;
         kp.indices = g->d_indices; kp.nnz = (int)g->nnz;
         kp.deg_shift = g->deg_shift; kp.node_mask = g->node_mask; kp.deg_sat = g->deg_sat;

@@ -1438,7 +1438,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
 }
 
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 6) gfpush_sk_kernel(const KParams)
+__global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : 6) gfpush_sk_kernel(const KParams)
 {
     gfpush_sk_rows<BLOCK>();
 }

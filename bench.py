@@ -581,8 +581,10 @@ def run_rank(args, platform=CudaPlatform, cold=None) -> int:
                 graph.gfpush_omp(hs, row, col, val, coef, recipe.rmax, K)
                 ts.append(time.perf_counter() - t1)
             med = sorted(ts[1:])[1]
+            k_same = graph.stats()["kernel_ms"]                  # (gp_gfpush reports its own call: the kernel time of THIS seed batch, not the timed steps' average)
             line["host_api"] = {"rows_per_s": round(per / med, 1), "ms_per_call": round(med * 1e3, 3), "rows_per_call": per,
-                                "first_call_ms": round(ts[0] * 1e3, 3),
+                                "first_call_ms": round(ts[0] * 1e3, 3), "kernel_ms_same_batch": round(k_same, 3),
+                                "call_over_kernel": round(med * 1e3 / k_same, 4) if k_same else None,
                                 "what": "Graph.gfpush_omp (gp_gfpush): int64 seeds on the host -> numpy row/col/value filled in place, median of 3 calls after one warm-up"}
         if cold is not None:
             line["cold_call"] = cold

@@ -18,5 +18,6 @@ GRANDPLUS_STRESS_REPS=30 GRANDPLUS_STRESS_ROWS=65536 timeout 900 python -m pytes
 cat gpurun_out/$TAG/soak.txt
 timeout 500 python tools/fuzz_sketch.py 400 > gpurun_out/$TAG/fuzz.txt 2>&1; tail -3 gpurun_out/$TAG/fuzz.txt
 FUZZ_KERNEL=1 timeout 300 python tools/fuzz_sketch.py 200 >> gpurun_out/$TAG/fuzz.txt 2>&1; tail -2 gpurun_out/$TAG/fuzz.txt
-timeout 1500 python tools/slow_propagate_runs.py ${SLOW_PROP_RUNS:-24} mag > gpurun_out/$TAG/slow_propagate.jsonl 2>&1; tail -1 gpurun_out/$TAG/slow_propagate.jsonl
+timeout 900 python tools/slow_propagate_runs.py ${SLOW_PROP_RUNS:-8} mag > gpurun_out/$TAG/slow_propagate.jsonl 2>&1; tail -1 gpurun_out/$TAG/slow_propagate.jsonl
+python tools/host_api_latency.py 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/host_api_latency.txt; tail -2 gpurun_out/$TAG/host_api_latency.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2

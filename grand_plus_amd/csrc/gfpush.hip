@@ -120,6 +120,7 @@ struct gp_graph {
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
     int kernel = 0;                                                        // option: 0 = choose per call, 1 = general kernel, 2 = sketch kernel whenever the call allows it
     int sk_block = 0, sk_lg_mu = 0, sk_lg_mr = 0, sk_target = 0, sk_direct_max = 0;   // options: geometry of the sketch kernel (0 = default)
+    int gk_acsr = 1;                                                       // option: the general kernel runs on the self-addressed copy too when the graph is large (0 = packed CSR + indptr)
     int est_kind = 0; int last_kind = 1; bool sk_auto_off = false; double sk_off_rmax = 0.0; int sk_off_n_coef = 0;                                   // which kernel the running estimate / the last call belongs to
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
@@ -968,6 +969,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "sk_direct_max") {
         if (value < 0 || value > (1 << 20)) return fail(GP_ERR_INVALID_ARG, "sk_direct_max must be in [0, 2^20]");
         g->sk_direct_max = (int)value;          // levels of up to this many edges insert straight into the exact table (0 = three quarters of its slots, the most the kernel allows)
+    } else if (k == "gk_acsr") {
+        g->gk_acsr = value ? 1 : 0;
     } else if (k == "sk_target") {
         if (value < 0 || value > 4096) return fail(GP_ERR_INVALID_ARG, "sk_target must be in [0, 4096]");
         g->sk_target = (int)value;
@@ -1238,6 +1241,25 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.direct = ((block_threads == 512 || block_threads == 768) && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
 
+    // Which copy of the graph a launch runs on.  The self-addressed one (round 6: also for the general kernel on large graphs -- no
+    // indptr line per pushing node, aligned runs: ~2 of the Amazon2M line's 13.6 MB per row) or the packed CSR + indptr.
+    bool gk_acsr = g->gk_acsr && !kp.direct && !g->force_global && g->n_nodes >= 65536 && n_seeds > 0;
+#ifndef GP_DIAG
+    if (gk_acsr) { rc = ensure_acsr(g, s); if (rc) return rc; gk_acsr = g->acsr_state == 1; }
+#else
+    gk_acsr = false;
+#endif
+    auto use_csr = [&](bool acsr, bool general) {
+        if (acsr) {
+            kp.indices = g->d_acsr; kp.nnz = (int)(g->n_units << 5);
+            kp.deg_shift = g->a_shift; kp.node_mask = g->a_mask; kp.deg_sat = g->a_sat;
+            kp.node_pos = g->d_node_pos; kp.unit_info = g->d_unit_info; kp.sk_hub_units = g->a_sat > 32u ? 1u : 0u;
+        } else {
+            kp.indices = g->d_indices; kp.nnz = (int)g->nnz;
+            kp.deg_shift = g->deg_shift; kp.node_mask = g->node_mask; kp.deg_sat = g->deg_sat;
+        }
+        kp.gk_acsr = acsr && general ? 1u : 0u;
+    };
     auto launch = [&](int wgs) {
         switch (block_threads) {
             case 256: return launch_kernel<256>(kp, wgs, lds_bytes + g->lds_pad, s);
@@ -1248,6 +1270,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     };
     HIP_TRY(hipEventRecord(g->ev0, s));
     if (n_seeds > 0 && !use_sk) {
+        use_csr(gk_acsr, true);
         use_slabs(w.est);
         kp.row_map = nullptr; kp.n_rows_dev = nullptr; kp.queue_counter = kQueue;
         kp.retry_list = two_tier ? w.retry_list : nullptr; kp.retry_counter = kRetryRows;
@@ -1279,13 +1302,10 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
             kp.sk_thr_f = t;
         }
         // ... on the self-addressed CSR: keys are unit numbers under the packed degree
-        kp.indices = g->d_acsr; kp.nnz = (int)(g->n_units << 5);
-        kp.deg_shift = g->a_shift; kp.node_mask = g->a_mask; kp.deg_sat = g->a_sat;
-        kp.node_pos = g->d_node_pos; kp.unit_info = g->d_unit_info; kp.sk_hub_units = g->a_sat > 32u ? 1u : 0u;
+        use_csr(true, false);
         rc = sk_block == 512 ? launch_sk<512>(kp, sk_wg, sk_lds + g->lds_pad, s) : sk_block == 1024 ? launch_sk<1024>(kp, sk_wg, sk_lds + g->lds_pad, s) : launch_sk<768>(kp, sk_wg, sk_lds + g->lds_pad, s);
         if (rc) return rc;
-        kp.indices = g->d_indices; kp.nnz = (int)g->nnz;
-        kp.deg_shift = g->deg_shift; kp.node_mask = g->node_mask; kp.deg_sat = g->deg_sat;
+        use_csr(gk_acsr, true);
         // 2. the general kernel over that list (a quarter of the chip: the list is a per-cent of the call); rows that outgrow
         //    ITS estimate-sized slabs go to retry_list2 ...
         use_slabs(w.est);
@@ -1586,7 +1606,7 @@ int replicate_part(gp_graph* g, int d) {
     q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
     q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
     q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges; q->seedrow = src->seedrow; q->solo_levels = src->solo_levels;
-    q->kernel = src->kernel; q->sk_block = src->sk_block; q->sk_lg_mu = src->sk_lg_mu; q->sk_lg_mr = src->sk_lg_mr; q->sk_target = src->sk_target; q->lds_pad = src->lds_pad; q->sk_direct_max = src->sk_direct_max;
+    q->kernel = src->kernel; q->gk_acsr = src->gk_acsr; q->sk_block = src->sk_block; q->sk_lg_mu = src->sk_lg_mu; q->sk_lg_mr = src->sk_lg_mr; q->sk_target = src->sk_target; q->lds_pad = src->lds_pad; q->sk_direct_max = src->sk_direct_max;
     const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));

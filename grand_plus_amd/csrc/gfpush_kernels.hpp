@@ -307,7 +307,8 @@ struct KParams {
     const u32* node_pos;                  // node -> first unit of its row (seeds)
     const int* unit_info;                 // first unit of a row -> node id (output columns); second unit of a multi-unit row -> its degree
     unsigned short* log_pu; double* arch; u64 arch_cap;   // per-workgroup: pusher number of every log record; coef * share of every pusher of the row
-    u32 sk_hub_units; u32 sk_pad;         // 1: deg >= deg_sat implies >= 2 units, the exact degree of a saturated node is unit_info[unit + 1]
+    u32 sk_hub_units; u32 gk_acsr;        // sk_hub_units 1: deg >= deg_sat implies >= 2 units, the exact degree of a saturated node is unit_info[unit + 1];
+                                          // gk_acsr 1 (round 6): the GENERAL kernel runs on the self-addressed copy too (keys are unit numbers; csr_row / out_col)
     int diag_flags;                       // GP_DIAG builds only (instruction attribution by difference): bit 0 = skip TOP-K, bit 1 = run EXPAND twice, bit 2 = walk the drained table once more
 };
 // The launch parameters where the hardware put them: the kernel argument segment (KParams is the kernels' only argument),
@@ -318,6 +319,21 @@ typedef const GP_KARG KParams& KP;
 static_assert(sizeof(KParams) % 8 == 0, "kparams(): the hidden kernel arguments must start right behind KParams");
 __device__ __forceinline__ KP kparams() {
     return *(const GP_KARG KParams*)((const GP_KARG char*)__builtin_amdgcn_implicitarg_ptr() - sizeof(KParams));
+}
+
+// Where the CSR row of the node behind a key starts and ends (graph.h:43-45, :96-97).  Packed CSR: two indptr words (one 128-byte
+// line per pushing node).  Self-addressed copy (round 6, KParams::gk_acsr): the row starts at the key's unit and the degree rides in
+// the key -- no memory access unless the degree field is saturated (then one word of unit_info / two of indptr).
+__device__ __forceinline__ void csr_row(KP p, u32 key, int& ds, int& de) {
+    const u32 id = key & p.node_mask;
+    if (p.gk_acsr) {
+        u32 deg = key >> p.deg_shift;
+        if (deg == p.deg_sat) {
+            if (p.sk_hub_units) deg = (u32)p.unit_info[id + 1u];
+            else { const int node = p.unit_info[id]; deg = (u32)(p.indptr[node + 1] - p.indptr[node]); }
+        }
+        ds = (int)(id << kSkUnitShift); de = ds + (int)deg;
+    } else { ds = p.indptr[id]; de = p.indptr[id + 1]; }
 }
 
 // ---------------------------------------------------------------- small helpers
@@ -863,9 +879,8 @@ __device__ __forceinline__ void scan_level(KP p, Ctl* ctl, LevelCtr* nx, int* lk
                 // exact degree known and the test fails => dropped without touching memory   (graph.h:94);
                 // a saturated field still says deg >= deg_sat, so r < rmax*deg_sat cannot push either
                 if (dq == 0u || r[u] >= p.rmax * (double)dq) {
-                    const int node = (int)((u32)k[u] & p.node_mask);
                     want_deg[u] = true;
-                    ds[u] = p.indptr[node]; de[u] = p.indptr[node + 1]; ++st_deg;           // graph.h:43-45
+                    csr_row(p, (u32)k[u], ds[u], de[u]); ++st_deg;                          // graph.h:43-45
                 }
             }
         }
@@ -1039,8 +1054,7 @@ __device__ __forceinline__ void scan_level_dense(KP p, Ctl* ctl, LevelCtr* nx, i
                 if (want[v]) {
                     k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
                     lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
-                    const int node = (int)((u32)k[v] & p.node_mask);
-                    ds[v] = p.indptr[node]; de[v] = p.indptr[node + 1]; ++st_deg;           // graph.h:43-45
+                    csr_row(p, (u32)k[v], ds[v], de[v]); ++st_deg;                          // graph.h:43-45
                 }
             }
 #pragma unroll
@@ -1741,7 +1755,7 @@ __device__ __forceinline__ void topk_row(KP p, Ctl* ctl, unsigned char* scratch,
         u32 rank = 0;
         for (u32 j = 0; j < need; ++j) rank += cand_better(sel[j], c) ? 1u : 0u;
         p.out_row[out0 + rank] = seed;                                           // graph.h:122
-        p.out_col[out0 + rank] = c.key;                                          // graph.h:123
+        p.out_col[out0 + rank] = p.gk_acsr ? p.unit_info[c.key] : c.key;         // graph.h:123 (unit numbers grow with node ids: the order is the same)
         p.out_val[out0 + rank] = __longlong_as_double((long long)c.bits);        // graph.h:124
     }
     publish_filled(p, row, need);
@@ -1934,8 +1948,9 @@ __device__ GP_PHASE_NOINLINE void phase_solo_level(u32 lds0, u32 lvl, u32 cur, u
         const bool cand = valid && (dq == 0u || r >= p.rmax * (double)dq);
         double share = 0.0; u32 len = 0, ds = 0;
         if (cand) {
-            const int node = (int)((u32)k & p.node_mask);
-            ds = (u32)p.indptr[node]; const u32 deg = (u32)p.indptr[node + 1] - ds; ++st_deg;          // graph.h:43-45
+            int ds_, de_;
+            csr_row(p, (u32)k, ds_, de_); ++st_deg;                                                   // graph.h:43-45
+            ds = (u32)ds_; const u32 deg = (u32)(de_ - ds_);
             if (deg == 0) {                                                                           // graph.h:91-93
                 __hip_atomic_fetch_add(&nx->dangling, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&nx->n_dangling, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2281,9 +2296,10 @@ __device__ __forceinline__ void gfpush_rows()
         };
 
         // the seed's table key carries its degree like every packed column id
-        const u32 s_start = uni((u32)p.indptr[seed]);
-        const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - s_start;
-        const int seed_key = (int)((u32)seed | (min(seed_deg, p.deg_sat) << p.deg_shift));
+        const u32 seed_deg = uni((u32)p.indptr[seed + 1]) - uni((u32)p.indptr[seed]);
+        const u32 seed_id = p.gk_acsr ? uni(p.node_pos[seed]) : (u32)seed;                 // (self-addressed copy: keys are unit numbers)
+        const u32 s_start = p.gk_acsr ? seed_id << kSkUnitShift : uni((u32)p.indptr[seed]);
+        const int seed_key = (int)(seed_id | (min(seed_deg, p.deg_sat) << p.deg_shift));
 #ifdef GP_DIAG
         if (tid == 0 && seed_deg != 0xFFFFFFFFu) rs1 = wall_clock64();     // after the queue -> seed -> indptr chain
 #endif

@@ -28,7 +28,7 @@ EXPORTS = (
     "gp_set_option", "gp_random_prop_rows", "gp_random_prop_coo", "gp_internal_set_error",
     "gp_propagate_features", "gp_internal_graph_csr", "gp_internal_diag_counters",
     "gp_graph_create_multi", "gp_graph_num_gpus", "gp_internal_multi_plan", "gp_internal_graph_acsr", "gp_graph_create_multi_on",
-    "gp_seed_positions", "gp_batch_positions", "gp_internal_create_ms",
+    "gp_seed_positions", "gp_batch_positions", "gp_internal_create_ms", "gp_internal_warm_device",
 )
 
 
@@ -139,6 +139,7 @@ def lib():
     L.gp_internal_diag_counters.restype = ctypes.c_int
     L.gp_internal_diag_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     _optional(L, "gp_internal_graph_acsr", [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)])
+    _optional(L, "gp_internal_warm_device", [ctypes.c_int])
     try:
         L.gp_internal_create_ms.restype = None
         L.gp_internal_create_ms.argtypes = [ctypes.POINTER(ctypes.c_double)]

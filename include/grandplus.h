@@ -204,8 +204,12 @@ int gp_reset_stats(gp_graph* g);
  *                      the call allows it (all coef >= 0, at most 40 levels, K <= 128, rmax > 0).  Automatic choice: the
  *                      sketch kernel for rmax >= 5e-6 on graphs of >= 65 536 nodes
  *   "sk_block_threads" / "sk_lg_mu" / "sk_lg_mr" / "sk_target"   geometry of the sketch kernel (0 = default): threads per
- *                      workgroup (512 = three per CU with 52 KB, 768 = two with 80 KB), log2 cells of the level sketch and
- *                      of the reserve sketch, cell rank of the first TOP-K threshold (default 4 K)
+ *                      workgroup (512 = three per CU with 52 KB, 768 = two with 80 KB, 1024 = one with 160 KB: measurements
+ *                      only), log2 cells of the level sketch and of the reserve sketch, cell rank of the first TOP-K
+ *                      threshold (default 4 K)
+ *   "gk_acsr"         0 = the general kernel always runs on the packed CSR + indptr (default 1: on graphs of >= 65 536 nodes
+ *                      it runs on the self-addressed copy -- rows at 128-byte units, a pusher's row start and degree in
+ *                      its key -- like the sketch kernel)
  *   "verify_merge"    1 = gp_gfpush (host buffers) compares every row it merged while the kernel was running with the pinned
  *                      slab once the launches have retired and fails with GP_ERR_HIP if one differs (a debugging aid: the
  *                      merge rule relies on stores to host memory arriving whole; default 0)
@@ -301,6 +305,8 @@ void gp_internal_set_error(int status, const char* where, const char* detail);
 /* Milliseconds the calling thread's last gp_graph_create spent: [0] HIP runtime + device, [1] allocations, [2] upload, [3] validation on
  * the device, [4] per-graph objects (bench.py's cold_call block). */
 void gp_internal_create_ms(double* out5);
+/* Starts the HIP runtime's context on `device` (hipSetDevice + hipFree(NULL)): what a process's first allocation otherwise pays. */
+int gp_internal_warm_device(int device);
 
 #ifdef __cplusplus
 }

@@ -120,7 +120,7 @@ struct gp_graph {
     int64_t workspace_mb = 65536; int force_global = 0; int exact_stats = 0; int diag_flags = 0; int direct_tables = 1; int seedrow = 1; int solo_levels = 1;
     int kernel = 0;                                                        // option: 0 = choose per call, 1 = general kernel, 2 = sketch kernel whenever the call allows it
     int sk_block = 0, sk_lg_mu = 0, sk_lg_mr = 0, sk_target = 0, sk_direct_max = 0;   // options: geometry of the sketch kernel (0 = default)
-    int gk_acsr = 1;                                                       // option: the general kernel runs on the self-addressed copy too when the graph is large (0 = packed CSR + indptr)
+    int sk_seed_merge = 1; int gk_acsr = 1;                                                       // option: the general kernel runs on the self-addressed copy too when the graph is large (0 = packed CSR + indptr)
     int est_kind = 0; int last_kind = 1; bool sk_auto_off = false; double sk_off_rmax = 0.0; int sk_off_n_coef = 0;                                   // which kernel the running estimate / the last call belongs to
     int64_t est_level_edges = 0;                                           // option: edges per level the first-launch slabs are sized for (0 = automatic)
     double est_edges = 0.0, est_log = 0.0;                                 // running estimate (grows from the observed maxima)
@@ -969,6 +969,8 @@ int gp_set_option(gp_graph* g, const char* key, int64_t value) {
     } else if (k == "sk_direct_max") {
         if (value < 0 || value > (1 << 20)) return fail(GP_ERR_INVALID_ARG, "sk_direct_max must be in [0, 2^20]");
         g->sk_direct_max = (int)value;          // levels of up to this many edges insert straight into the exact table (0 = three quarters of its slots, the most the kernel allows)
+    } else if (k == "sk_seed_merge") {
+        g->sk_seed_merge = value ? 1 : 0;
     } else if (k == "gk_acsr") {
         g->gk_acsr = value ? 1 : 0;
     } else if (k == "sk_target") {
@@ -1236,7 +1238,7 @@ int gp_gfpush_device(gp_graph* g, const int32_t* d_seeds, int64_t n_seeds,
     kp.prune = g->exact_stats ? 0 : 1;
     kp.diag_flags = g->diag_flags;
     kp.rows_distinct = g->rows_distinct && g->seedrow ? 1u : 0u;
-    kp.solo = g->solo_levels ? 1u : 0u;
+    kp.solo = (g->solo_levels ? 1u : 0u) | (g->sk_seed_merge ? 2u : 0u);      // (bit 1: the sketch kernel's wave 0 does level 1 in the call of level 0)
     // direct-indexed level tables: the whole graph fits the table of the 512-thread kernel (Cora, Citeseer)
     kp.direct = ((block_threads == 512 || block_threads == 768) && (u64)g->n_nodes + 4 <= (u64)lds_slots && g->direct_tables) ? 1 : 0;
     for (int i = 0; i < n_coef; ++i) if (coef[i] < 0.0) kp.prune = 0;      // the bound needs coef >= 0
@@ -1606,7 +1608,7 @@ int replicate_part(gp_graph* g, int d) {
     q->block_threads = src->block_threads; q->lds_bytes = src->lds_bytes; q->max_workgroups = src->max_workgroups;
     q->workspace_mb = src->workspace_mb; q->force_global = src->force_global; q->exact_stats = src->exact_stats;
     q->direct_tables = src->direct_tables; q->est_level_edges = src->est_level_edges; q->seedrow = src->seedrow; q->solo_levels = src->solo_levels;
-    q->kernel = src->kernel; q->gk_acsr = src->gk_acsr; q->sk_block = src->sk_block; q->sk_lg_mu = src->sk_lg_mu; q->sk_lg_mr = src->sk_lg_mr; q->sk_target = src->sk_target; q->lds_pad = src->lds_pad; q->sk_direct_max = src->sk_direct_max;
+    q->kernel = src->kernel; q->gk_acsr = src->gk_acsr; q->sk_seed_merge = src->sk_seed_merge; q->sk_block = src->sk_block; q->sk_lg_mu = src->sk_lg_mu; q->sk_lg_mr = src->sk_lg_mr; q->sk_target = src->sk_target; q->lds_pad = src->lds_pad; q->sk_direct_max = src->sk_direct_max;
     const size_t b_ptr = sizeof(int) * (size_t)(q->n_nodes + 1), b_idx = sizeof(int) * (size_t)(q->nnz + 1);     // with the sentinel word
     HIP_TRY(hipMalloc(&q->d_indptr, b_ptr));
     HIP_TRY(hipMalloc(&q->d_indices, b_idx));

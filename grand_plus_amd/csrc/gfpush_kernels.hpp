@@ -2435,7 +2435,7 @@ __device__ __forceinline__ void gfpush_rows()
             }
             // a small level: one wave does it, the others park at one barrier (phase_solo_level)
             bool solo_done = false;
-            if (in_lds && !direct && parts == 1 && !lvl_seedrow && !use_buckets && p.solo &&
+            if (in_lds && !direct && parts == 1 && !lvl_seedrow && !use_buckets && (p.solo & 1u) &&
                 e_cur <= kSoloEdges && n_ent_cur >= 1u && n_ent_cur <= kSoloEntries && !uni(ctl->fail) &&
                 solo_caps && (u64)log_pos + kSoloEdges + 2u <= p.log_cap) {
                 GP_STAMP(t0);

@@ -700,9 +700,12 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
 // call and park at the one barrier behind it (the general path: two calls per wave, two barriers, a table walk).  An insert
 // that hits the probe limit (ctl->ovf) undoes the claims; the caller then re-streams the level in hash partitions.
 constexpr u32 kSkSoloEdges = 256;
-template <int BLOCK>
+// SEED (round 6): level 1 straight behind level 0, in the same call of wave 0 (phase_sk_seed): its one entry -- the seed --
+// arrives in (seed_rel, seed_share) instead of being read back from the push list the same wave has just written.
+template <int BLOCK, bool SEED = false>
 __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u32 E, u32 seg_base, double cs,
-                                                u32 has_dang, double dang, int seed_key, u32 nx_sel, u32 pu_base, u32 pu_next, double cnext)
+                                                u32 has_dang, double dang, int seed_key, u32 nx_sel, u32 pu_base, u32 pu_next, double cnext,
+                                                u32 seed_rel = 0, double seed_share = 0.0)
 {
     KP p = kparams();
     lds0 = uni(lds0); cur = uni(cur); n_ent = uni(n_ent); E = uni(E); seg_base = uni(seg_base); cs = uni(cs);
@@ -722,7 +725,9 @@ __device__ GP_PHASE_NOINLINE void phase_sk_solo(u32 lds0, u32 cur, u32 n_ent, u3
     u32* bt_nxt = w.bt2 + (u64)(cur ^ 1u) * (u32)p.bt_cap;
     int* lk = w.log_key + seg_base; unsigned short* lp = w.log_pu + seg_base;
     // ---- the one step of the edge enumeration (as sk_edge_stream: entries flag their first edge, ballot, mbcnt, bpermute)
-    const PushEntry ent = push_cur[min(lane, n_ent - 1u)];
+    PushEntry ent;
+    if (SEED) { ent.rel = uni(seed_rel); ent.off = 0u; ent.share = uni(seed_share); }
+    else ent = push_cur[min(lane, n_ent - 1u)];
     const u32 off = lane < n_ent ? ent.off : 0xFFFFFFFFu;
     *(u32*)(wscr + 4 * lane) = 0u;
     if (off > 0u && off < E) wscr[(off & 63u) * 4u + (off >> 6)] = 1;
@@ -1160,8 +1165,11 @@ __device__ __forceinline__ u64 sk_io_pack(u32 pu_next, u32 log_next) { return ((
 
 // Level 0 of a row: the frontier is { seed : 1.0 } (graph.h:81): its record, push test and push-list entry directly; what it
 // leaves for level 1 goes where every level leaves it: lc[0].
+// Returns 1 when level 1 is done as well (round 6): a seed of <= 256 edges that pushes makes level 1 a one-wave level whatever
+// else is true, so wave 0 does it straight behind level 0 -- same call, no barrier, no level prologue of twelve waves, the seed's
+// entry in registers -- and the other waves, who know the seed's degree too, go to the one barrier.  The row goes on at level 2.
 template <int BLOCK>
-__device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
+__device__ GP_PHASE_NOINLINE u32 phase_sk_seed(u32 lds0, int seed)
 {
     KP p = kparams();
     lds0 = uni(lds0); seed = uni(seed);
@@ -1184,6 +1192,12 @@ __device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
         if (tid == 0) { zstat(ctl, zPush, 1); zstat(ctl, zEdges, seed_deg); }
     }
     const u32 units = (seed_deg + (1u << kUnitShift) - 1u) >> kUnitShift;
+    // level 1 in this call?  (what phase_sk_level would decide for it, from values every wave has: nothing of it depends on LDS
+    //  another thread writes in this phase)
+    const u32 k_lc = uni(ctl->k_log_cap), k_so = uni(ctl->k_solo_ok), k_dm = uni(ctl->k_direct_max);
+    const bool merged = (p.solo & 2u) != 0u && k_so != 0u && pushes && room && L >= 2u && seed_deg <= kSkSoloEdges && seed_deg <= k_dm &&
+                        (u64)units <= p.bt_cap && (u64)1u + seed_deg <= (u64)k_lc && (u64)2u + kSkSoloEdges + 4u <= (u64)pu_cap;
+    if (merged && wave_id() != 0u) return 1u;
     if (tid == 0) {
         ctl->seed_key = seed_key; ctl->tot_pu = 1; ctl->tot_log = 1;
         if (room) { w.log_key[0] = seed_key; w.log_pu[0] = 0; w.arch[0] = ctl->coef[0]; }      // graph.h:90
@@ -1200,6 +1214,18 @@ __device__ GP_PHASE_NOINLINE void phase_sk_seed(u32 lds0, int seed)
     }
     if (pushes && (u64)units <= p.bt_cap)
         for (u32 m = (u32)tid; m < units; m += BLOCK) { bt1[m] = 0u; if (m < w.bt_l_cap) w.bt_l[m] = 0u; }
+    if (!merged) return 0u;
+    // ---- level 1 by this wave (wave 0), as phase_sk_level would run it: the prologue's writes, then the one-wave level
+    if (tid == 0) {
+        LevelCtr* nx = &ctl->lc[1];
+        nx->dangling = 0.0; nx->n_dangling = 0; nx->n_rec = 0; nx->alloc = 0ull; nx->pad1 = sk_io_pack(2u, 1u + seed_deg);
+        ctl->tot_pu = 2u; ctl->tot_log = 1u + seed_deg; ctl->max_e = max(ctl->max_e, seed_deg);
+        ctl->lv_has_dang = 0u; ctl->lv_dang = 0.0;
+        zstat(ctl, zLevels, 1);
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);                       // (one wave: its LDS operations execute in program order)
+    phase_sk_solo<BLOCK, true>(lds0, 1u, 1u, seed_deg, 1u, ctl->coef[1] * ctl->k_rscale, 0u, 0.0, seed_key, 1u, 1u, 2u, ctl->coef[2], s_start, share);
+    return 1u;
 }
 
 // One level l = 1..L of a row (graph.h:83-110).  Returns 0 when the row's levels are done (last level, dead frontier, or the row
@@ -1368,7 +1394,7 @@ __device__ __forceinline__ void gfpush_sk_rows()
         ctl->k_direct_max = min(p.sk_direct_max, 3u * (w.CX / 4u)); ctl->k_cx = w.CX; ctl->k_rscale = p.sk_rscale;
         // a one-wave level must not be able to hit a workspace bound other than through its own checks: the boundary table must
         // hold the largest level any frontier can produce -- degrees pushed in one level sum to <= 1/rmax, SURVEY.md A.1
-        ctl->k_solo_ok = p.solo && p.push_cap >= (u64)kSkSoloEdges + 4u &&
+        ctl->k_solo_ok = (p.solo & 1u) && p.push_cap >= (u64)kSkSoloEdges + 4u &&
                          (double)p.bt_cap >= (p.rmax > 0.0 ? fmin((double)p.nnz, 1.001 / p.rmax + 16.0) : (double)p.nnz) / (double)(1u << kUnitShift) + 4.0 ? 1u : 0u;
     }
     const long long n_rows = p.n_seeds;
@@ -1389,10 +1415,11 @@ __device__ __forceinline__ void gfpush_sk_rows()
             if (tid == 0) { __hip_atomic_fetch_add(&ctl->st[zFailed], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p.out_filled) p.out_filled[row] = 0; }
             continue;
         }
-        phase_sk_seed<BLOCK>(lds0, seed);
+        u32 lvl = 1u + uni(phase_sk_seed<BLOCK>(lds0, seed));                     // (2: wave 0 has done level 1 as well)
         GP_SYNC();
         SKT(ctl, 0); SKT_COUNT(ctl, 15, 1);
-        for (u32 lvl = 1; lvl <= L; ++lvl)
+        if (lvl == 2u) { SKT_COUNT(ctl, 13, 1); if (uni(ctl->ovf)) lvl = 1u; }   // (an insert at the probe limit: the claims are undone, level 1 takes the general path)
+        for (; lvl <= L; ++lvl)
             if (!uni(phase_sk_level<BLOCK>(lds0, lvl, L))) break;
         GP_SYNC();
         SKT(ctl, 6);

@@ -735,3 +735,24 @@ def test_small_levels_by_one_wave_equal_the_workgroup_path():
     exp, ost = _oracle(ip, ix, sd, coef, 0.0, 8, fill=(-1, -1, -1.0))
     _assert_parity(sd, 8, got, exp, fill=(-1, -1, -1.0))
     assert st["pushes"] == ost["pushes"] and st["frontier"] == ost["frontier_sum"]
+
+
+@pytest.mark.parametrize("opts", [{"gk_acsr": 1}, {"gk_acsr": 0},
+                                  {"gk_acsr": 1, "block_threads": 1024, "lds_bytes": 163840}, {"gk_acsr": 1, "seedrow": 0, "solo_levels": 0}])
+def test_general_kernel_on_the_self_addressed_csr_and_on_the_packed_one(opts):
+    """Round 6: on graphs of >= 65 536 nodes the general kernel runs on the self-addressed copy of the CSR (csr_row: a pusher's row
+    start and degree come from its key; output columns go back through unit_info) -- option gk_acsr = 0 keeps the packed copy and
+    its indptr lookups.  Both against the oracle: random seeds, the twelve largest hubs (saturated degree fields: the exact degree
+    comes from unit_info), duplicate seeds; rmax 1e-6 (nothing filtered: the Amazon2M regime) and 1e-5."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import make_coef
+    indptr, indices = synth.shape_csr("small")                  # 100 000 nodes
+    deg = np.diff(indptr)
+    seeds = np.concatenate([synth.seeds(len(indptr) - 1, 200), np.argsort(deg)[-12:], [7, 7]]).astype(np.int64)
+    for rmax, K, coef in ((1e-6, 64, make_coef("ppr", 4, 0.2)), (1e-5, 32, make_coef("avg", 6, 0.2))):
+        got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options=dict(opts, kernel=1))
+        exp, ost = _oracle(indptr, indices, seeds, coef, rmax, K)
+        assert st["kernel"] == 1
+        _assert_parity(seeds, K, got, exp, label=f"general kernel {opts} rmax {rmax}")
+        assert (st["pushes"], st["edges"], st["filled"]) == (ost["pushes"], ost["edges"], ost["filled"]), (opts, st, ost)
+        assert st["failed_rows"] == 0

@@ -39,6 +39,22 @@ def test_sketch_kernel_synthetic_small(mode, order, alpha, rmax, K, block):
         assert 0 < st["sketch_candidate_edges"] < st["edges"]          # levels large enough for the sketch exist, and it removes something
 
 
+@pytest.mark.parametrize("opts", [{"sk_seed_merge": 0}, {"sk_seed_merge": 1, "solo_levels": 0}, {"sk_seed_merge": 1, "sk_direct_max": 1}])
+def test_level_one_in_the_call_of_level_zero_and_without_it(opts):
+    """Round 6: wave 0 does level 1 in the call of level 0 when the seed has <= 256 edges (phase_sk_seed).  The same rows with the
+    option off, with one-wave levels off (then level 1 takes the general path), with a direct limit of one edge (level 1 is a
+    sketch level); seeds include the largest hubs (more than 256 edges: not merged) and a dangling-free duplicate."""
+    from grand_plus_amd import synth
+    from grand_plus_amd.recipes import RECIPES
+    indptr, indices = synth.shape_csr("small")
+    deg = np.diff(indptr)
+    seeds = np.concatenate([synth.seeds(len(indptr) - 1, 1000), np.argsort(deg)[-6:], [11, 11]]).astype(np.int64)
+    r = RECIPES[("mag", "ppr")]
+    _check(indptr, indices, seeds, r.coef(), r.rmax, r.top_k, dict(SK, **opts), label=f"seed merge {opts}")
+    # two levels only: level 1 is the LAST level (never merged: its edges are only recorded)
+    _check(indptr, indices, seeds[:64], r.coef()[:2] / r.coef()[:2].sum(), r.rmax, r.top_k, dict(SK, **opts), label=f"seed merge, L = 1 {opts}")
+
+
 def test_sketch_kernel_is_the_default_for_filtering_recipes_on_large_graphs():
     from grand_plus_amd import synth
     from grand_plus_amd.recipes import RECIPES

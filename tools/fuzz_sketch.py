@@ -48,6 +48,7 @@ while time.time() - t0 < budget:
     if g == 3: opts.update(sk_target=int(rng.choice([1, 8, 64, 1024])))
     if g == 4: opts.update(sk_direct_max=int(rng.choice([1, 64, 100000])))
     if g == 5: opts.update(sk_lg_mu=9, sk_lg_mr=8)
+    if case % 5 == 4: opts.update(sk_seed_merge=0) if opts["kernel"] == 2 else opts.update(gk_acsr=0)    # (round 6) the paths the new defaults replace
     if case % 2: opts.update(max_workgroups=int(rng.choice([3, 8, 64])))       # a workgroup takes MANY rows one after the other (round 5: state left behind by a row)
     label = f"fuzz {case}: n {n} nnz {len(indices)} {mode} L{L} rmax {rmax:.2e} K{K} {opts}"
     got, st = _run_gpu(indptr, indices, seeds, coef, rmax, K, options=opts)

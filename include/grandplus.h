@@ -101,6 +101,10 @@ int         gp_device_count(void);        /* number of visible HIP devices (0 if
  * here the caller may free them after the call) and derives degrees on the fly from indptr
  * (graph.h:42-45).  The reference's unused `seed` argument (graph.h:40) is accepted by the
  * shims and dropped before this call.
+ * indptr is checked on the host (O(N)); the column ids are checked on the DEVICE behind the upload (range; and whether
+ * every row is strictly increasing, which only decides a shortcut): GP_ERR_INVALID_CSR either way, before the handle exists.
+ * Arrays of >= 64 MB are uploaded through four 16 MB pinned staging buffers filled by two helper threads, joined before
+ * the call returns.
  */
 int gp_graph_create(const int32_t* indptr, int64_t n_nodes,
                     const int32_t* indices, int64_t nnz,
@@ -148,7 +152,9 @@ int     gp_graph_device(const gp_graph* g);
  * the filled slots are i = 0..filled-1 ordered by (value desc, column asc) -- the reference
  * leaves that order unspecified (nth_element, graph.h:115).  Synchronous.  The calling thread merges
  * finished rows into the caller's arrays while the kernels run; one helper thread, joined before the
- * call returns, resets the pinned slab the next call will use.  No OpenMP, no process-wide settings.
+ * call returns, resets the pinned slab the next call will use.  No OpenMP, no process-wide settings: the one
+ * thing the call touches outside its own memory is the CALLING THREAD's timer slack (prctl PR_SET_TIMERSLACK,
+ * 1 us while it waits for rows in 60 us sleeps; put back before the call returns).
  */
 int gp_gfpush(gp_graph* g,
               const int32_t* seeds, int64_t n_seeds,

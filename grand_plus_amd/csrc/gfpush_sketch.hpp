@@ -603,58 +603,44 @@ __device__ GP_PHASE_NOINLINE void phase_sk_scan(u32 lds0, u32 cap, u32 nx_sel, u
     constexpr u32 kWaves = BLOCK / 64;
     const u32 range = ((cap + kWaves * 256u - 1u) / (kWaves * 256u)) * 256u;
     const u32 wb = wave_id() * range;
-    u32 tot = 0;
+    // (round 6) ONE pass: the slots of my range are read four per lane, cleared, and what passes the cheap half of the push test --
+    // the exact degree is in the key unless the field is saturated (graph.h:94) -- is compacted to the front of the range.  (Until
+    // round 5 the occupied slots were compacted first and tested in a second pass over them: one more LDS write / read round per call.)
+    u32 tot = 0, ncand = 0;
+    const double rmax_ = p.rmax; const u32 dsh = (u32)p.deg_shift;
     for (u32 sub = wb; sub < wb + range && sub < cap; sub += 256u) {
         const u32 s0 = sub + 4u * (u32)lane;
         i4 kk = {kEmpty, kEmpty, kEmpty, kEmpty};
         if (s0 < cap) kk = *(const i4*)&lkeys[s0];                  // (cap % 4 == 0)
         const bool o0 = kk.x != kEmpty, o1 = kk.y != kEmpty, o2 = kk.z != kEmpty, o3 = kk.w != kEmpty;
-        const u64 m0 = __ballot(o0), m1 = __ballot(o1), m2 = __ballot(o2), m3 = __ballot(o3);
-        const u32 c0 = (u32)__popcll(m0), c1 = (u32)__popcll(m1), c2 = (u32)__popcll(m2), c3 = (u32)__popcll(m3);
-        if (c0 + c1 + c2 + c3 == 0) continue;                       // wave-uniform
+        const u32 n_occ = (u32)__popcll(__ballot(o0)) + (u32)__popcll(__ballot(o1)) + (u32)__popcll(__ballot(o2)) + (u32)__popcll(__ballot(o3));
+        if (n_occ == 0) continue;                                   // wave-uniform
+        tot += n_occ;
+        d2 ra = {0.0, 0.0}, rb = {0.0, 0.0};
         if (o0 | o1 | o2 | o3) {
-            const d2 ra = *(const d2*)&lvals[s0], rb = *(const d2*)&lvals[s0 + 2];
+            ra = *(const d2*)&lvals[s0]; rb = *(const d2*)&lvals[s0 + 2];
             const i4 ke = {kEmpty, kEmpty, kEmpty, kEmpty};
             const d2 z = {0.0, 0.0};
             *(i4*)&lkeys[s0] = ke; *(d2*)&lvals[s0] = z; *(d2*)&lvals[s0 + 2] = z;
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);                // clears stay ahead of the staging stores
-            const u32 q0 = wb + tot;                                // [wb, wb + tot) lies inside the slots drained so far
-            if (o0) { const u32 q = q0 + lane_prefix(m0);                lkeys[q] = kk.x; lvals[q] = ra.x; }
-            if (o1) { const u32 q = q0 + c0 + lane_prefix(m1);           lkeys[q] = kk.y; lvals[q] = ra.y; }
-            if (o2) { const u32 q = q0 + c0 + c1 + lane_prefix(m2);      lkeys[q] = kk.z; lvals[q] = rb.x; }
-            if (o3) { const u32 q = q0 + c0 + c1 + c2 + lane_prefix(m3); lkeys[q] = kk.w; lvals[q] = rb.y; }
         }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                    // clears stay ahead of the staging stores
+        const u32 d0 = (u32)kk.x >> dsh, d1 = (u32)kk.y >> dsh, d2_ = (u32)kk.z >> dsh, d3 = (u32)kk.w >> dsh;
+        const bool c0b = o0 && (d0 == 0u || ra.x >= rmax_ * (double)d0), c1b = o1 && (d1 == 0u || ra.y >= rmax_ * (double)d1),
+                   c2b = o2 && (d2_ == 0u || rb.x >= rmax_ * (double)d2_), c3b = o3 && (d3 == 0u || rb.y >= rmax_ * (double)d3);
+        const u64 m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
+        const u32 c0 = (u32)__popcll(m0), c1 = (u32)__popcll(m1), c2 = (u32)__popcll(m2), c3 = (u32)__popcll(m3);
+        const u32 q0 = wb + ncand;                                  // [wb, wb + ncand) lies inside the slots drained so far
+        if (c0b) { const u32 q = q0 + lane_prefix(m0);                lkeys[q] = kk.x; lvals[q] = ra.x; }
+        if (c1b) { const u32 q = q0 + c0 + lane_prefix(m1);           lkeys[q] = kk.y; lvals[q] = ra.y; }
+        if (c2b) { const u32 q = q0 + c0 + c1 + lane_prefix(m2);      lkeys[q] = kk.z; lvals[q] = rb.x; }
+        if (c3b) { const u32 q = q0 + c0 + c1 + c2 + lane_prefix(m3); lkeys[q] = kk.w; lvals[q] = rb.y; }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        tot += c0 + c1 + c2 + c3;
+        ncand += c0 + c1 + c2 + c3;
     }
     (void)C;
     u32 st_push = 0, st_edges = 0, st_deg = 0;
     SKT2(ctl, 5);
     if (tot != 0) {
-        // the cheap half of the push test: the exact degree is in the key unless the field is saturated (graph.h:94)
-        u32 ncand = 0;
-        for (u32 j = 0; j < tot; j += 128u) {
-            int k[2]; double r[2]; bool cnd[2];
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const u32 idx = j + 64u * (u32)v + (u32)lane;
-                k[v] = kEmpty; r[v] = 0.0; cnd[v] = false;
-                if (idx < tot) {
-                    k[v] = lkeys[wb + idx]; r[v] = lvals[wb + idx];
-                    lkeys[wb + idx] = kEmpty; lvals[wb + idx] = 0.0;
-                    const u32 dq = (u32)k[v] >> p.deg_shift;
-                    cnd[v] = dq == 0u || r[v] >= p.rmax * (double)dq;
-                }
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);                // reads and clears stay ahead of the list stores
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const u64 m = __ballot(cnd[v]);
-                if (cnd[v]) { const u32 q = wb + ncand + lane_prefix(m); lkeys[q] = k[v]; lvals[q] = r[v]; }
-                ncand += (u32)__popcll(m);                          // <= nodes consumed so far: stays inside cleared slots
-            }
-        }
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         SKT2(ctl, 6);
         for (u32 j = 0; j < ncand; j += 64u) {
             const u32 idx = j + (u32)lane;
